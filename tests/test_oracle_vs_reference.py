@@ -71,3 +71,21 @@ def R_back_project(up_coords, sc, sdfnet, feats, HW):
     T = torch.from_numpy
     KR = T(sc["affine_mats"])[:, None]
     return R.back_project_sparse_type(up_coords, T(sc["partial_vol_origin"])[None], sdfnet.voxel_size, feats[:, None], KR, sizeH=HW, sizeW=HW)
+
+
+@torch.no_grad()
+def test_gen_rays_matches_reference():
+    """a15: synth.gen_rays (numpy host code of the product's data prep) == gen_rays_from_single_image (models/rays.py:11-54)."""
+    import importlib
+    pkg = importlib.import_module("one-2-3-45_amd")
+    R = RI.load()
+    for (H, W, seed) in [(40, 40, 0), (24, 36, 3), (256, 256, 5)]:
+        sc = pkg.synth.make_scene(4, hw=(H, W), image_seed=seed)
+        K, c2w = torch.from_numpy(sc["query_intrinsic"]), torch.from_numpy(sc["query_c2w"])
+        ref = R.gen_rays_from_single_image(H, W, torch.zeros(3, H, W), K, c2w)
+        ro, rd = pkg.synth.gen_rays(sc["query_intrinsic"], sc["query_c2w"], H, W)
+        assert ro.shape == tuple(ref["rays_o"].shape) and rd.shape == tuple(ref["rays_v"].shape)
+        assert np.array_equal(ro, ref["rays_o"].numpy())
+        # numpy's float32 inverse / matmul vs ATen's: same algorithm, last-bit differences at most
+        assert np.abs(rd - ref["rays_v"].numpy()).max() < 3e-7
+        assert np.abs(np.linalg.norm(rd, axis=-1) - 1).max() < 3e-7
