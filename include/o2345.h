@@ -123,6 +123,10 @@ int o2345_sdf_grad_x3(const float* blob, const float* vol_cl, int D, const float
  * Per-sample arrays are sample-major [S][R]. */
 int o2345_ray_coarse(const float* rays_o, const float* rays_d, int R, float near, float far, int S, float* z, float* pts,
                      void* stream);
+/* the same with the reference's stratified jitter (models/sparse_neus_renderer.py:506-515): t_rand [R][S] (ray-major, what
+ * torch.rand(z_vals.shape) returns) or NULL */
+int o2345_ray_coarse_jitter(const float* rays_o, const float* rays_d, int R, float near, float far, int S,
+                            const float* t_rand, float* z, float* pts, void* stream);
 int o2345_ray_upsample(const float* rays_o, const float* rays_d, int R, const float* z, const float* sdf, int S,
                        float inv_s, const float* maskvol, int D, float* wbuf, int n_imp, float* new_z, float* new_pts,
                        float* new_sdf, int32_t* list, int32_t* count_dev, void* stream);
@@ -151,6 +155,7 @@ typedef struct O2345RenderIO {
     int sdf_bf16;                   /* SDF network mode: 0 exact fp32 MFMA; 1 bf16 throughput mode; 2 split-f16 ("f16x3", fp32-class
                                      * accuracy: o2345_sdf_mlp_x3 / o2345_sdf_grad_x3) */
     const float* color_x3_blob;     /* optional: split-f16 colour kernel (takes precedence over color_mfma_blob; V <= 32) */
+    const float* t_rand;            /* optional [R][n_samples]: the reference's perturb > 0 jitter, drawn by the caller (ABI 1.2) */
 } O2345RenderIO;
 size_t o2345_render_workspace_bytes(int R, int n_samples, int n_importance);
 int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace_bytes, void* stream);

@@ -47,7 +47,7 @@ class RenderIO(ctypes.Structure):
                 [(n, ctypes.c_void_p) for n in ("mid_z", "dists", "pm", "sdf", "grad", "rgb", "nviews", "color", "depth",
                                                 "weights", "cdf", "weights_sum", "weights_max", "depth_var", "alpha_sum",
                                                 "grad_err", "color_mask", "z_vals", "color_mfma_blob")] +
-                [("sdf_bf16", ctypes.c_int), ("color_x3_blob", ctypes.c_void_p)])
+                [("sdf_bf16", ctypes.c_int), ("color_x3_blob", ctypes.c_void_p), ("t_rand", ctypes.c_void_p)])
 
 
 _LIB = None

@@ -487,13 +487,7 @@ static int color_mfma_launch(bool x3, const float* blob, const float* vol_cl, co
     ColorMArgs a{blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews};
     int G = 4;
     while (G < V) G <<= 1;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = cu_count();
     const int threads = 768, ppt = 32 / G;
     const long long per_block = (long long)(threads / 64) * ppt;
     long long want = n_dev ? n_cu : (n + per_block - 1) / per_block;

@@ -40,6 +40,20 @@ inline int check_launch(const char* what) {
 
 inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
+// Compute units of the CURRENT device (the one the caller's stream belongs to), cached per device ordinal: persistent kernels
+// size their grids from it, and one process may drive several GPUs.
+inline int cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 // wave64 helpers --------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return __lane_id(); }
 

@@ -11,12 +11,23 @@
 namespace o2345 {
 
 // coarse samples: z = near + (far-near) * linspace(0,1,S)  and their points, point index p = s*R + r
-__global__ __launch_bounds__(256) void k_ray_coarse(RayGeom g, float near, float far, int S, float* __restrict__ z,
-                                                    float* __restrict__ pts) {
+// t_rand (optional): the reference's stratified jitter (sparse_neus_renderer.py:506-515).  The reference draws
+// t_rand = torch.rand(z_vals.shape) on the HOST ([R][S], ray-major) and sets z = lower + (upper - lower) * t_rand with
+// lower/upper the midpoints to the neighbouring coarse samples; the caller hands the same tensor over, so the path is
+// bit-reproducible under torch.manual_seed.
+__global__ __launch_bounds__(256) void k_ray_coarse(RayGeom g, float near, float far, int S, const float* __restrict__ t_rand,
+                                                    float* __restrict__ z, float* __restrict__ pts) {
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= (long long)S * g.R) return;
     const int s = (int)(p / g.R), r = (int)(p % g.R);
-    const float zz = near + (far - near) * linspace_at(0.f, 1.f, S, s);
+    float zz = near + (far - near) * linspace_at(0.f, 1.f, S, s);
+    if (t_rand) {
+        const float zp = near + (far - near) * linspace_at(0.f, 1.f, S, s > 0 ? s - 1 : 0);
+        const float zn = near + (far - near) * linspace_at(0.f, 1.f, S, s < S - 1 ? s + 1 : S - 1);
+        const float lower = s > 0 ? 0.5f * (zz + zp) : zz;            // mids = .5 * (z[1:] + z[:-1])
+        const float upper = s < S - 1 ? 0.5f * (zn + zz) : zz;
+        zz = lower + (upper - lower) * t_rand[(long long)r * S + s];
+    }
     z[p] = zz;
     float x, y, w;
     ray_point(g, r, zz, x, y, w);
@@ -155,11 +166,16 @@ int o2345_view_count(const float* pts, long long n, const float* maskvol, int D,
                      uint8_t* out, void* stream);
 
 // ---- stage entry points (used by the parity tests; the orchestrator below calls the same kernels) -----------------
-int o2345_ray_coarse(const float* rays_o, const float* rays_d, int R, float near, float far, int S, float* z, float* pts, void* stream) {
+int o2345_ray_coarse_jitter(const float* rays_o, const float* rays_d, int R, float near, float far, int S, const float* t_rand,
+                            float* z, float* pts, void* stream) {
     O2345_REQUIRE(rays_o && rays_d && z && pts && R > 0 && S > 1, "ray_coarse: bad arguments");
     RayGeom g{rays_o, rays_d, R};
-    hipLaunchKernelGGL(k_ray_coarse, dim3(cdiv((long long)R * S, 256)), dim3(256), 0, (hipStream_t)stream, g, near, far, S, z, pts);
+    hipLaunchKernelGGL(k_ray_coarse, dim3(cdiv((long long)R * S, 256)), dim3(256), 0, (hipStream_t)stream, g, near, far, S, t_rand, z, pts);
     return check_launch("ray_coarse");
+}
+
+int o2345_ray_coarse(const float* rays_o, const float* rays_d, int R, float near, float far, int S, float* z, float* pts, void* stream) {
+    return o2345_ray_coarse_jitter(rays_o, rays_d, R, near, far, S, nullptr, z, pts, stream);
 }
 
 int o2345_ray_upsample(const float* rays_o, const float* rays_d, int R, const float* z, const float* sdf, int S, float inv_s,
@@ -228,6 +244,7 @@ struct O2345RenderIO {
     const float* color_mfma_blob;
     int sdf_bf16;               // SDF network mode: 0 fp32 MFMA, 1 bf16 (sdf_mlp_bf16.hip), 2 split-f16 forward (sdf_mlp_x3.hip)
     const float* color_x3_blob; // optional: split-f16 colour kernel
+    const float* t_rand;        // optional [R][n_samples]: stratified jitter of the coarse samples (perturb > 0)
 };
 
 int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace_bytes, void* stream) {
@@ -235,6 +252,8 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     const int R = io->R, NS = io->n_samples, NIMP = io->n_importance;
     O2345_REQUIRE(NIMP % 4 == 0 && NIMP > 0 && NS > 1, "render_rays: n_importance must be a positive multiple of 4");
     O2345_REQUIRE(workspace_bytes >= o2345_render_workspace_bytes(R, NS, NIMP), "render_rays: workspace too small");
+    O2345_REQUIRE(R > 0 && ((long long)NS + NIMP) * (long long)R < 2147483647LL, "render_rays: R * (n_samples + n_importance) must stay below 2^31 "
+                  "(sample slots are 32-bit); split the ray batch (got R = %d)", R);
     const size_t S = (size_t)NS + NIMP, NI = NIMP / 4, RR = R;
     float* z = (float*)workspace;
     float* sdf = z + S * RR;
@@ -253,7 +272,7 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
         return hb ? o2345_sdf_mlp_bf16(variant, io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, grad, stream)
                   : o2345_sdf_mlp(variant, io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, nullptr, nullptr, grad, stream);
     };
-    if ((rc = o2345_ray_coarse(io->rays_o, io->rays_d, R, io->near, io->far, NS, z, pts, stream))) return rc;
+    if ((rc = o2345_ray_coarse_jitter(io->rays_o, io->rays_d, R, io->near, io->far, NS, io->t_rand, z, pts, stream))) return rc;
     // coarse SDF on ALL points (not masked, :525-528)
     if ((rc = sdf_eval(0, pts, nullptr, nullptr, (long long)NS * R, sdf, nullptr))) return rc;
     int cur = NS;

@@ -250,13 +250,7 @@ int o2345_sdf_mlp_bf16(int variant, const float* blob, const float* vol_cl, int 
     O2345_REQUIRE(variant != VAR_GRAD || out_grad, "sdf_mlp_bf16: gradient variant needs out_grad");
     if (n <= 0 && !n_dev) return 0;
     SdfArgs a{blob, vol_cl, D, pts, index, n_dev, n, grid_R, sign, out_sdf, nullptr, nullptr, out_grad, nullptr};
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = cu_count();
     const int threads = 512;
     const long long per_block = (threads / 64) * 32;
     long long want = n_dev ? n_cu : (n + per_block - 1) / per_block;

@@ -448,13 +448,7 @@ int o2345_sdf_grad_x3(const float* blob, const float* vol_cl, int D, const float
     O2345_REQUIRE(pts || (grid_R >= 2 && grid_R <= 1600), "sdf_grad_x3: need points or a grid resolution in [2, 1600]");
     if (n <= 0 && !n_dev) return 0;
     SdfArgs a{blob, vol_cl, D, pts, index, n_dev, n, grid_R, sign, out_sdf, nullptr, nullptr, out_grad, nullptr};
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = cu_count();
     const int threads = 512;
     const long long per_block = (threads / 64) * 32;
     long long want = n_dev ? n_cu : (n + per_block - 1) / per_block;
@@ -472,13 +466,7 @@ int o2345_sdf_mlp_x3(const float* blob, const float* vol_cl, int D, const float*
     O2345_REQUIRE(pts || (grid_R >= 2 && grid_R <= 1600), "sdf_mlp_x3: need points or a grid resolution in [2, 1600]");
     if (n <= 0 && !n_dev) return 0;
     SdfArgs a{blob, vol_cl, D, pts, index, n_dev, n, grid_R, sign, out_sdf, nullptr, nullptr, nullptr, nullptr};
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = cu_count();
     const int threads = 512;
     const long long per_block = (threads / 64) * 32;
     long long want = n_dev ? n_cu : (n + per_block - 1) / per_block;

@@ -172,13 +172,7 @@ int o2345_sparse_conv3d_x3(int mode, const float* in, int cin, const int32_t* in
     hipStream_t s = (hipStream_t)stream;
     Lattice3 lin{gx, gy, gz};
     dim3 grid(cdiv(n_out, 128));
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        O2345_HIP(hipGetDevice(&dev));
-        O2345_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = cu_count();
     const unsigned want = cdiv(n_out, 32 * 16);                       // 16 tiles (waves) per persistent workgroup round
     dim3 pgrid(want < (unsigned)n_cu ? want : (unsigned)n_cu);
     O2345_CONVX_CASE(32, 16) O2345_CONVX_CASE(16, 16) O2345_CONVX_CASE(16, 32) O2345_CONVX_CASE(32, 32)

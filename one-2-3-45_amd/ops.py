@@ -1,6 +1,7 @@
 """Torch-tensor wrappers over the C ABI (include/o2345.h).  PyTorch is plumbing only: device memory + streams.
 Every function validates dtype / device / contiguity, passes raw pointers, and raises on a non-zero status."""
 import ctypes
+import functools
 
 import numpy as np
 import torch
@@ -10,7 +11,34 @@ from ._lib import check
 
 
 def _stream():
+    """The current HIP stream of the CURRENT device; every public op runs under _on_device, which makes the device of its
+    tensor arguments current first (the C side sizes persistent grids from hipGetDevice())."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _first_cuda_tensor(objs):
+    for o in objs:
+        if torch.is_tensor(o):
+            if o.is_cuda:
+                return o
+        elif isinstance(o, dict):
+            t = _first_cuda_tensor(o.values())
+            if t is not None:
+                return t
+    return None
+
+
+def _on_device(fn):
+    """Run the op with the device of its (first) CUDA tensor argument current, so that the launch stream, the workspace and
+    the C side's device queries all refer to the tensors' device even when the caller never called torch.cuda.set_device."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        t = _first_cuda_tensor(list(args) + list(kw.values()))
+        if t is None:
+            raise ValueError(f"o2345 ops.{fn.__name__}: needs CUDA tensors (the HIP library has no CPU fallback)")
+        with torch.cuda.device(t.device):
+            return fn(*args, **kw)
+    return wrapped
 
 
 def _p(t, dtype=torch.float32):
@@ -34,7 +62,8 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device, tag="ws"):
-    key = (tag, str(device))
+    """Scratch buffer per (purpose, device, stream): two streams of one device never share scratch memory."""
+    key = (tag, str(device), torch.cuda.current_stream(device).cuda_stream)
     t = _ws_cache.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
@@ -43,6 +72,7 @@ def _workspace(nbytes, device, tag="ws"):
 
 
 # ---------------------------------------------------------------------------------------------------------- cost volume
+@_on_device
 def nchw_to_nhwc(x):
     V, C, H, W = x.shape
     out = torch.empty(V, H, W, C, device=x.device, dtype=torch.float32)
@@ -50,6 +80,7 @@ def nchw_to_nhwc(x):
     return out
 
 
+@_on_device
 def costvol_index(proj, V, H, W, dims, voxel_size, origin, min_views=1):
     """-> cnt u8 [D^3], row_of_voxel i32 [D^3], coords i32 [N,4] (x,y,z,b), N (python int; one 4-byte D2H read)."""
     L = _lib.lib()
@@ -70,6 +101,7 @@ def costvol_index(proj, V, H, W, dims, voxel_size, origin, min_views=1):
     return cnt, row, coords[:n], n
 
 
+@_on_device
 def costvol_gather(feats_nhwc, proj, dims, voxel_size, origin, cnt, coords):
     V, H, W, C = feats_nhwc.shape
     n = coords.shape[0]
@@ -83,6 +115,7 @@ def costvol_gather(feats_nhwc, proj, dims, voxel_size, origin, cnt, coords):
     return out
 
 
+@_on_device
 def visible_count_list(proj, H, W, voxel_size, origin, coords):
     """coords [M,4] int32 (x,y,z,b), any order -> number of views that see each listed voxel (u8 [M])."""
     M = coords.shape[0]
@@ -95,6 +128,7 @@ def visible_count_list(proj, H, W, voxel_size, origin, coords):
     return cnt
 
 
+@_on_device
 def costvol_gather_list(feats_nhwc, proj, voxel_size, origin, cnt_row, coords):
     V, H, W, C = feats_nhwc.shape
     n = coords.shape[0]
@@ -107,6 +141,7 @@ def costvol_gather_list(feats_nhwc, proj, voxel_size, origin, cnt_row, coords):
     return out
 
 
+@_on_device
 def build_index_grid(coords, ts, cells):
     nx, ny, nz = (int(c) for c in cells)
     grid = torch.empty(nx * ny * nz, dtype=torch.int32, device=coords.device)
@@ -115,12 +150,14 @@ def build_index_grid(coords, ts, cells):
     return grid
 
 
+@_on_device
 def prune_dilate(sdf_vol, mask_vol, D, threshold, radius=3):
     out = torch.empty(D * D * D, dtype=torch.uint8, device=sdf_vol.device)
     check(_lib.lib().o2345_prune_dilate(_p(sdf_vol), _p(mask_vol), D, float(threshold), int(radius), _p(out, torch.uint8), _stream()), "prune_dilate")
     return out
 
 
+@_on_device
 def scatter_dense(rows, row_of_voxel, dims, want_cf=True):
     dx, dy, dz = (int(d) for d in dims)
     nvox, C = dx * dy * dz, rows.shape[1]
@@ -136,6 +173,7 @@ def scatter_dense(rows, row_of_voxel, dims, want_cf=True):
 
 
 # ---------------------------------------------------------------------------------------------------------- sparse CNN
+@_on_device
 def sparse_downsample(coords, ts, fine_cells):
     """coords [n,4] int32 at tensor stride ts on a lattice of fine_cells cells/axis -> (grid, coords_c, n_c, cells_c)."""
     L = _lib.lib()
@@ -157,6 +195,7 @@ def sparse_downsample(coords, ts, fine_cells):
     return grid, cc[:n], n, nc
 
 
+@_on_device
 def sparse_conv3d(mode, x, in_grid, in_cells, out_coords, ts_out, kernel):
     n_out, cin, cout = out_coords.shape[0], x.shape[1], kernel.shape[2]
     out = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
@@ -167,6 +206,7 @@ def sparse_conv3d(mode, x, in_grid, in_cells, out_coords, ts_out, kernel):
     return out
 
 
+@_on_device
 def sparse_conv3d_x3(mode, x, in_grid, in_cells, out_coords, ts_out, wblob, cout):
     """Matrix-core form of sparse_conv3d (csrc/sparse_mfma.hip); wblob = weights.pack_sparse_conv_x3(kernel) on the device."""
     n_out, cin = out_coords.shape[0], x.shape[1]
@@ -178,6 +218,7 @@ def sparse_conv3d_x3(mode, x, in_grid, in_cells, out_coords, ts_out, wblob, cout
     return out
 
 
+@_on_device
 def bn_act_rows(x, gamma, beta, eps=1e-5, slope=0.0, abs_gamma=False, skip=None, want_stats=False):
     L = _lib.lib()
     n, C = x.shape
@@ -192,6 +233,7 @@ def bn_act_rows(x, gamma, beta, eps=1e-5, slope=0.0, abs_gamma=False, skip=None,
     return (y, mv) if want_stats else y
 
 
+@_on_device
 def abn_nchw(x, gamma, beta, eps=1e-5, slope=0.01, abs_gamma=True, want_nchw=True, want_nhwc=False):
     L = _lib.lib()
     V, C, H, W = x.shape
@@ -205,6 +247,7 @@ def abn_nchw(x, gamma, beta, eps=1e-5, slope=0.01, abs_gamma=True, want_nchw=Tru
 
 
 # ---------------------------------------------------------------------------------------------------------- SDF network
+@_on_device
 def sdf_mlp(blob, vol_cl, pts=None, variant=0, grid_R=0, sign=1.0, index=None, n_dev=None, want_lat=False, out=None, lat_in=None,
             precision=None):
     """variant 0: sdf; 1: sdf + 128 features; 2: sdf + gradient.  pts [P,3] or grid_R.  lat_in [P,16]: given latents instead of
@@ -253,6 +296,7 @@ def sdf_mlp(blob, vol_cl, pts=None, variant=0, grid_R=0, sign=1.0, index=None, n
 
 
 # ---------------------------------------------------------------------------------------------------------- colour
+@_on_device
 def pack_color_maps(feat_nchw, color_nchw):
     V, _, H, W = feat_nchw.shape
     out = torch.empty(V, H, W, 64, dtype=torch.float32, device=feat_nchw.device)
@@ -260,6 +304,7 @@ def pack_color_maps(feat_nchw, color_nchw):
     return out
 
 
+@_on_device
 def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=None, normals=None, index=None, n_dev=None,
                  want_nviews=True, mfma=False):
     """mfma=False: VALU kernel (blob from weights.pack_color_blob); mfma=True: fp32 matrix-core kernel (pack_color_mfma_blob,
@@ -279,6 +324,7 @@ def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=Non
     return rgb, nv
 
 
+@_on_device
 def view_count(pts, maskvol, D, proj, V, H, W):
     out = torch.empty(pts.shape[0], dtype=torch.uint8, device=pts.device)
     check(_lib.lib().o2345_view_count(_p(pts), pts.shape[0], _p(maskvol), D, _p(proj), V, H, W, _p(out, torch.uint8), _stream()), "view_count")
@@ -286,12 +332,33 @@ def view_count(pts, maskvol, D, proj, V, H, W):
 
 
 # ---------------------------------------------------------------------------------------------------------- rays
+@_on_device
 def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64, inv_s=None, alpha_inter_ratio=1.0,
-                background=1.0, query_cam=None, want_z=False):
+                background=1.0, query_cam=None, want_z=False, t_rand=None):
     """scene: dict(sdf_blob, color_blob, vol_cl, maskvol [D^3], cmaps, proj [V,3,4], cam_pos [V,3]).
-    Returns dict of SAMPLE-MAJOR tensors ([S,R,...]) + per-ray results."""
+    t_rand [R, n_samples] (optional): the reference's stratified jitter of the coarse samples (perturb > 0,
+    sparse_neus_renderer.py:506-515), drawn by the caller.  Returns dict of SAMPLE-MAJOR tensors ([S,R,...]) + per-ray results."""
     L = _lib.lib()
     R = rays_o.shape[0]
+    if query_cam is None:
+        raise ValueError("render_rays: query_cam [3] (the query camera centre, query_c2w[:3, 3]) is required")
+    if inv_s is None:
+        raise ValueError("render_rays: inv_s is required")
+    if rays_d.shape != rays_o.shape or rays_o.dim() != 2 or rays_o.shape[1] != 3:
+        raise ValueError(f"render_rays: rays_o / rays_d must both be [R,3] (got {tuple(rays_o.shape)}, {tuple(rays_d.shape)})")
+    if (n_samples + n_importance) * R >= 2 ** 31:
+        raise ValueError("render_rays: R * (n_samples + n_importance) must stay below 2^31; split the ray batch")
+    for k in ("sdf_blob", "color_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos"):
+        _p(scene[k])                                   # contiguous cuda float32, or ValueError
+        if scene[k].device != rays_o.device:
+            raise ValueError(f"render_rays: scene[{k!r}] is on {scene[k].device}, the rays on {rays_o.device}")
+    Dv = scene["vol_cl"].shape[0]
+    if scene["vol_cl"].dim() != 4 or scene["maskvol"].numel() != Dv ** 3 or scene["cmaps"].dim() != 4 or scene["cmaps"].shape[-1] != 64:
+        raise ValueError("render_rays: vol_cl [D,D,D,C], maskvol [D^3], cmaps [V,H,W,64] expected")
+    if tuple(scene["proj"].shape) != (scene["cmaps"].shape[0], 3, 4) or tuple(scene["cam_pos"].shape) != (scene["cmaps"].shape[0], 3):
+        raise ValueError("render_rays: proj [V,3,4] and cam_pos [V,3] must match the V of cmaps")
+    if t_rand is not None and tuple(t_rand.shape) != (R, n_samples):
+        raise ValueError(f"render_rays: t_rand must be [R, n_samples] = {(R, n_samples)}, got {tuple(t_rand.shape)}")
     S = n_samples + n_importance
     dev = rays_o.device
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -305,9 +372,10 @@ def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64,
     io = _lib.RenderIO()
     for k in ("sdf_blob", "color_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos"):
         setattr(io, k, scene[k].data_ptr())
-    io.color_mfma_blob = scene["color_mfma_blob"].data_ptr() if scene.get("color_mfma_blob") is not None else None
+    io.color_mfma_blob = _p(scene["color_mfma_blob"]).value if scene.get("color_mfma_blob") is not None else None
     use_x3 = scene.get("color_x3_blob") is not None and config.color_precision(scene.get("color_precision")) == "f16x3"
-    io.color_x3_blob = scene["color_x3_blob"].data_ptr() if use_x3 else None
+    io.color_x3_blob = _p(scene["color_x3_blob"]).value if use_x3 else None
+    io.t_rand = _p(t_rand).value if t_rand is not None else None
     io.sdf_bf16 = {"fp32": 0, "bf16": 1, "f16x3": 2}[config.sdf_precision(scene.get("sdf_precision"))]
     io.D, io.V, io.H, io.W = scene["vol_cl"].shape[0], V, H, W
     io.rays_o, io.rays_d, io.R = _p(rays_o).value, _p(rays_d).value, R
@@ -326,6 +394,7 @@ def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64,
 
 
 # ---------------------------------------------------------------------------------------------------------- marching cubes
+@_on_device
 def mesh_pack(verts_idx, tris, grid_R, bound_min=(-1.0, -1.0, -1.0), bound_max=(1.0, 1.0, 1.0), scale_mat=None, trans_mat=None, rgb=None):
     """Index-space vertices (fp64 [N,3]) + triangles -> (vertex records uint8 [N,16|12], face records uint8 [M,13]) of a binary PLY;
     frame transforms and colour quantisation as in trainer_generic.py:1365-1377.  Matrices / bounds are small host arrays."""
@@ -346,6 +415,7 @@ def mesh_pack(verts_idx, tris, grid_R, bound_min=(-1.0, -1.0, -1.0), bound_max=(
     return vrec, frec
 
 
+@_on_device
 def marching_cubes(u, iso=0.0, index_dtype=torch.int64):
     """u: float32 cuda tensor [n0,n1,n2].  Returns (verts float64 [Nv,3] index coords, tris [Nt,3]) on the device."""
     L = _lib.lib()

@@ -10,18 +10,28 @@ from .costreg import CostRegNet
 from .featurenet import ConvBnReLU, FeatureNet, fused_pyramid
 
 
+def _load_checked(module, sd, what):
+    """load_state_dict that only tolerates absent BatchNorm running buffers (the reference runs in training mode and this back end
+    never reads them): a renamed / missing parameter must not silently leave seeded stand-in weights in place."""
+    res = module.load_state_dict(sd, strict=False)
+    missing = [k for k in res.missing_keys if not ("running_" in k or "num_batches_tracked" in k)]
+    if missing or res.unexpected_keys:
+        raise KeyError(f"{what}: checkpoint does not match (missing {missing}, unexpected {list(res.unexpected_keys)})")
+
+
 class SceneWeights:
     """All network parameters of one lod-0 model on the device (seeded stand-ins unless state dicts are given)."""
 
     def __init__(self, device, seed=0, sdf=None, color_sd=None, costreg_sd=None, variance=0.2, sdf_precision=None, color_precision=None):
-        torch.manual_seed(seed)
         self.device = device
         sdf_precision = config.sdf_precision(sdf_precision)
         color_precision = config.color_precision(color_precision)
         self.color_precision = color_precision    # "f16x3" (default) | "fp32": see config.py
         self.sdf_precision = sdf_precision        # "f16x3" (default) | "fp32" | "bf16": see config.py
-        self.featurenet = FeatureNet().to(device)
-        self.compress = ConvBnReLU(56, 16).to(device)
+        with torch.random.fork_rng(devices=[]):         # seeded stand-in initialisation must not reset the caller's global RNG
+            torch.manual_seed(seed)
+            self.featurenet = FeatureNet().to(device)
+            self.compress = ConvBnReLU(56, 16).to(device)
         self.sdfW = sdf or weights.init_sdf_weights(seed)
         self.color_sd = color_sd or weights.init_color_state_dict(seed)
         self.costreg_sd = costreg_sd or weights.init_costreg_state_dict(seed)
@@ -43,9 +53,9 @@ class SceneWeights:
         self = cls(device, seed=0, sdf=weights.sdf_weights_from_state_dict(sd, "sdf_layer."),
                    color_sd={k: t(v).numpy() for k, v in rendering_network_sd.items()}, costreg_sd=costreg, variance=float(variance))
         comp = {k[len("compress_layer."):]: v for k, v in sd.items() if k.startswith("compress_layer.")}
-        self.compress.load_state_dict(comp, strict=False)
+        _load_checked(self.compress, comp, "compress_layer")
         if featurenet_sd is not None:
-            self.featurenet.load_state_dict({k: t(v) for k, v in featurenet_sd.items()}, strict=False)
+            _load_checked(self.featurenet, {k: t(v) for k, v in featurenet_sd.items()}, "pyramid_feature_network")
         return self
 
 
@@ -74,12 +84,15 @@ def camera_terms(intrinsics, w2cs):
 
 
 @torch.no_grad()
-def render(wt, vol, proj, cam_pos, rays_o, rays_d, near, far, query_cam, n_samples=64, n_importance=64, want_z=False):
+def render(wt, vol, proj, cam_pos, rays_o, rays_d, near, far, query_cam, n_samples=64, n_importance=64, want_z=False, t_rand=None):
+    """One call renders all rays (no 512-ray chunks).  ``t_rand`` [R, n_samples]: the reference's perturb > 0 jitter (drawn by the caller).
+    Note: the reference's per-512-ray-chunk quirks (cat_z_vals skipped when <= 1 new point of the CHUNK is valid; "first 100 points"
+    when a chunk has no valid point) apply per CALL here -- identical when called per chunk, as the drop-in mirror does."""
     scene = dict(sdf_blob=wt.sdf_blob, color_blob=wt.color_blob, vol_cl=vol["vol_cl"], maskvol=vol["maskvol"],
                  cmaps=vol["cmaps"], proj=proj, cam_pos=cam_pos, color_mfma_blob=wt.color_mblob if proj.shape[0] <= 32 else None,
                  sdf_precision=wt.sdf_precision, color_precision=wt.color_precision,
                  color_x3_blob=wt.color_xblob if proj.shape[0] <= 32 else None)
-    return ops.render_rays(scene, rays_o, rays_d, near, far, n_samples, n_importance, wt.inv_s, 1.0, 1.0, query_cam, want_z)
+    return ops.render_rays(scene, rays_o, rays_d, near, far, n_samples, n_importance, wt.inv_s, 1.0, 1.0, query_cam, want_z, t_rand=t_rand)
 
 
 @torch.no_grad()

@@ -107,20 +107,26 @@ class SparseNeuSRenderer(nn.Module):
                color_maps=None, w2cs=None, intrinsics=None, img_wh=None, query_c2w=None, if_general_rendering=True,
                if_render_with_grad=True, img_index=None, rays_uv=None, pre_sample=False, bg_ratio=0.0):
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
-        if perturb > 0 or pre_sample or bg_ratio > 0 or not if_general_rendering:
-            raise NotImplementedError("o2345 render: deterministic inference path only (perturb_overwrite=0, general rendering); the "
-                                      "reference's stochastic jitter (perturb=1.0, :508-515) has no reproducible counterpart")
+        if pre_sample or bg_ratio > 0 or not if_general_rendering:
+            raise NotImplementedError("o2345 render: general rendering without pre_sample / bg_ratio (the released val / export configuration)")
         cm, proj, cam_pos = _scene_maps(feature_maps, color_maps, w2cs, intrinsics)
         R = rays_o.shape[0]
+        # stratified jitter exactly as the reference draws it (:506-515): torch.rand(z_vals.shape) on the HOST generator, then moved to
+        # the device -> the same numbers as the reference under the same torch.manual_seed; the kernel applies lower + (upper-lower)*t
+        t_rand = torch.rand(R, self.n_samples).to(rays_o.device) if perturb > 0 else None
         scene = dict(sdf_blob=sdf_network.sdf_layer.blob(), color_blob=rendering_network.blob(), vol_cl=channel_last(conditional_volume),
                      maskvol=conditional_valid_mask_volume.reshape(-1).contiguous().float(), cmaps=cm, proj=proj, cam_pos=cam_pos,
                      color_mfma_blob=rendering_network.mfma_blob() if proj.shape[0] <= 32 else None,
                      color_x3_blob=rendering_network.x3_blob() if proj.shape[0] <= 32 else None)
         inv_s = float(torch.exp(self.variance_network.variance.detach() * 10.0).clip(1e-6, 1e6))
-        nr, fr = float(torch.as_tensor(near).reshape(-1)[0]), float(torch.as_tensor(far).reshape(-1)[0])
+        nt, ft = torch.as_tensor(near).reshape(-1).float(), torch.as_tensor(far).reshape(-1).float()
+        if nt.numel() > 1 and (bool((nt != nt[0]).any()) or bool((ft != ft[0]).any())):
+            raise NotImplementedError("o2345 render: one near / far pair per call (the runner passes the query view's [1] tensors); "
+                                      "per-ray near / far are not supported")
+        nr, fr = float(nt[0]), float(ft[0])
         o = ops.render_rays(scene, rays_o.contiguous().float(), rays_d.contiguous().float(), nr, fr, self.n_samples, self.n_importance,
                             inv_s, float(alpha_inter_ratio), 1.0 if background_rgb is None else float(background_rgb),
-                            query_c2w.reshape(-1, 4, 4)[0, :3, 3].contiguous().float())
+                            query_c2w.reshape(-1, 4, 4)[0, :3, 3].contiguous().float(), t_rand=t_rand)
         S = self.n_samples + self.n_importance
         pm = o["pm"].t()
         ge = o["grad_err"].sum(0)

@@ -493,13 +493,19 @@ def rendering_network(RW, geo, rgb_feat, rdiff, mask):
 
 
 # ----------------------------------------------------------------------------------------------
-# a16, a21: render / render_core (sparse_neus_renderer.py:171-635), perturb = 0, general rendering
+# a16, a21: render / render_core (sparse_neus_renderer.py:171-635), general rendering; perturb > 0 when t_rand is given
 # ----------------------------------------------------------------------------------------------
 def render(rays_o, rays_d, near, far, volume, maskvol, W, RW, variance, feat_maps, color_maps, w2cs, K, img_wh,
-           query_c2w, n_samples=64, n_importance=64, alpha_inter_ratio=1.0, background_rgb=1.0):
+           query_c2w, n_samples=64, n_importance=64, alpha_inter_ratio=1.0, background_rgb=1.0, t_rand=None):
+    """t_rand [R, n_samples]: the stratified jitter of :506-515 (the reference draws torch.rand(z_vals.shape) on the host)."""
     R = rays_o.shape[0]
     sample_dist = float((far - near) / n_samples)
     z = (near + (far - near) * torch.linspace(0, 1, n_samples))[None].repeat(R, 1)
+    if t_rand is not None:
+        mids = 0.5 * (z[:, 1:] + z[:, :-1])
+        upper = torch.cat([mids, z[:, -1:]], 1)
+        lower = torch.cat([z[:, :1], mids], 1)
+        z = lower + (upper - lower) * t_rand
     pts = (rays_o[:, None] + rays_d[:, None] * z[..., None]).reshape(-1, 3)
     s = sdf(pts, volume, W)[0][:, 0].reshape(R, n_samples)     # coarse pass is NOT masked (:525-528)
     for i in range(4):

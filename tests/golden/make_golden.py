@@ -35,11 +35,9 @@ def inputs(cfg=CFG):
     return sc, fmaps, pts, ro[sel].copy(), rd[sel].copy()
 
 
-def main():
-    torch.set_grad_enabled(False)
-    cfg = CFG
-    sc, fmaps, pts, ro, rd = inputs()
-    D, HW = cfg["D"], cfg["HW"]
+def networks(cfg=CFG):
+    """The seeded reference networks of the golden scene (same construction for every golden file)."""
+    D = cfg["D"]
     sdfnet, rnet, var, renderer = RI.build_networks(D, seed=cfg["seed"])
     # the reference zero-initialises latent / PE columns: perturb them (seeded) so that every path is exercised
     g = torch.Generator().manual_seed(cfg["seed"])
@@ -53,6 +51,51 @@ def main():
             m.bias.data = 0.1 * torch.randn(m.bias.shape, generator=g)
     sdfnet.compress_layer.bn.weight.data = -(1 + 0.2 * torch.randn(16, generator=g))     # negative: exercises |gamma|
     sdfnet.compress_layer.bn.bias.data = 0.1 * torch.randn(16, generator=g)
+    return sdfnet, rnet, var, renderer
+
+
+def main_perturb(seed=1234):
+    """tests/golden/ref_perturb.npz: the reference's DEFAULT val path -- render() with perturb = 1.0 (confs/one2345_lod0_val_demo.conf:127,
+    trainer_generic.py:505-523 passes no perturb_overwrite) under torch.manual_seed(seed).  The reference draws the jitter with
+    torch.rand(z_vals.shape) on the host generator (sparse_neus_renderer.py:506-515), first random draw of the call."""
+    torch.set_grad_enabled(False)
+    cfg = CFG
+    sc, fmaps, pts, ro, rd = inputs()
+    HW = cfg["HW"]
+    sdfnet, rnet, var, renderer = networks(cfg)
+    T = torch.from_numpy
+    cv = sdfnet.get_conditional_volume(feature_maps=T(fmaps)[None], partial_vol_origin=T(sc["partial_vol_origin"])[None],
+                                       proj_mats=T(sc["affine_mats"])[None], sizeH=HW, sizeW=HW, lod=0)
+    dense, mask = cv["dense_volume_scale0"], cv["valid_mask_volume_scale0"]
+    here = os.path.dirname(os.path.abspath(__file__))
+    g0 = np.load(os.path.join(here, "ref_small.npz"))
+    assert np.array_equal(g0["dense"], dense[0].numpy()) and np.array_equal(g0["mask"], mask[0, 0].numpy()), "scene differs from ref_small.npz"
+    near, far = T(sc["query_near_far"][:1]), T(sc["query_near_far"][1:])
+    assert renderer.perturb == 1.0
+    torch.manual_seed(seed)
+    ren = renderer.render(T(ro), T(rd), near, far, sdfnet, rnet, background_rgb=1.0, alpha_inter_ratio=1.0,        # perturb_overwrite = -1
+                          lod=0, conditional_volume=dense, conditional_valid_mask_volume=mask, feature_maps=T(fmaps),
+                          color_maps=T(sc["images"]), w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW],
+                          query_c2w=T(sc["query_c2w"])[None], if_render_with_grad=False)
+    torch.manual_seed(seed)
+    t_rand = torch.rand(len(ro), 64)
+    out = {"seed": np.int64(seed), "t_rand": t_rand.numpy()}
+    for k in ("color_fine", "depth", "weights", "gradients", "sdf", "weights_sum", "depth_variance", "cdf_fine", "color_fine_mask",
+              "weights_max", "inside_sphere"):
+        out["ren_" + k] = ren[k].numpy()
+    out["ren_alpha_sum"] = np.float32(ren["alpha_sum"])
+    path = os.path.join(here, "ref_perturb.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; colour differs from the deterministic render by",
+          float(np.abs(out["ren_color_fine"] - g0["ren_color_fine"]).max()))
+
+
+def main():
+    torch.set_grad_enabled(False)
+    cfg = CFG
+    sc, fmaps, pts, ro, rd = inputs()
+    D, HW = cfg["D"], cfg["HW"]
+    sdfnet, rnet, var, renderer = networks(cfg)
     T = torch.from_numpy
     out = {}
     cv = sdfnet.get_conditional_volume(feature_maps=T(fmaps)[None], partial_vol_origin=T(sc["partial_vol_origin"])[None],
@@ -131,4 +174,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main_perturb() if "--perturb" in sys.argv else main()

@@ -66,6 +66,30 @@ def test_render(G):
 
 
 @torch.no_grad()
+def test_render_perturbed(G):
+    """The reference's DEFAULT val path (perturb = 1.0): tests/golden/ref_perturb.npz was rendered by the reference under
+    torch.manual_seed(seed); the jitter tensor is the first draw of the call (sparse_neus_renderer.py:506-515)."""
+    import os
+    gp = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_perturb.npz"))
+    g, sc, cfg = G["g"], G["sc"], G["cfg"]
+    W = {k: torch.from_numpy(v) for k, v in sdf_weights(G).items()}
+    HW = cfg["HW"]
+    T = torch.from_numpy
+    torch.manual_seed(int(gp["seed"]))
+    t_rand = torch.rand(len(G["ro"]), 64)
+    assert np.array_equal(t_rand.numpy(), gp["t_rand"]), "torch's CPU generator stream changed"
+    out = O.render(T(G["ro"]), T(G["rd"]), T(sc["query_near_far"][:1]), T(sc["query_near_far"][1:]), T(g["dense"]), T(g["mask"]), W,
+                   G["ren_sd"], G["var_sd"]["variance"], T(G["fmaps"]), T(sc["images"]), T(sc["w2cs"]), T(sc["intrinsics"]), (HW, HW),
+                   T(sc["query_c2w"]), t_rand=t_rand)
+    for k, tol in (("color_fine", 2e-6), ("depth", 2e-6), ("weights", 2e-6), ("weights_sum", 2e-6), ("depth_variance", 2e-6),
+                   ("cdf_fine", 2e-6), ("weights_max", 2e-6)):
+        assert mx(out[k], gp["ren_" + k]) < tol, k
+    assert mx(out["sdf"], gp["ren_sdf"]) < 1e-5
+    assert np.array_equal(out["color_fine_mask"].numpy(), gp["ren_color_fine_mask"])
+    assert mx(out["color_fine"], g["ren_color_fine"]) > 1e-3            # and it is NOT the deterministic image
+
+
+@torch.no_grad()
 def test_vertex_colour(G):
     g, sc, cfg = G["g"], G["sc"], G["cfg"]
     W = {k: torch.from_numpy(v) for k, v in sdf_weights(G).items()}

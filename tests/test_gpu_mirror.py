@@ -79,8 +79,24 @@ def test_render_and_mesh(S):
     assert out["weights"].shape == g["ren_weights"].shape and out["gradients"].shape == g["ren_gradients"].shape
     assert out["sdf"].shape == g["ren_sdf"].shape and out["color_fine_mask"].shape == g["ren_color_fine_mask"].shape
     assert rel(out["alpha_sum"], g["ren_alpha_sum"]) < 1e-3
-    with pytest.raises(NotImplementedError):       # stochastic path is refused loudly, never silently approximated
-        S["ren"].render(T(G["ro"]), T(G["rd"]), 0.0, 1.0, S["sdf"], S["rnet"], lod=0)
+    # the reference's DEFAULT val path: perturb = 1.0 from the conf, no perturb_overwrite (trainer_generic.py:505-523); the jitter is
+    # drawn from torch's host generator exactly like sparse_neus_renderer.py:506-515 -> reproduces the reference under the same seed
+    import os
+    gp = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_perturb.npz"))
+    assert S["ren"].perturb == 1.0
+    torch.manual_seed(int(gp["seed"]))
+    outp = S["ren"].render(T(G["ro"]), T(G["rd"]), T(sc["query_near_far"][:1]), T(sc["query_near_far"][1:]), S["sdf"], S["rnet"],
+                           background_rgb=1.0, alpha_inter_ratio=1.0, lod=0, conditional_volume=dense,
+                           conditional_valid_mask_volume=mask, feature_maps=T(G["fmaps"]), color_maps=T(sc["images"]), w2cs=T(sc["w2cs"]),
+                           intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW], query_c2w=T(sc["query_c2w"])[None], if_render_with_grad=False)
+    for k in ("color_fine", "depth", "weights_sum", "depth_variance"):
+        assert rel(outp[k], gp["ren_" + k]) < 1e-3, "perturbed " + k
+    assert rel(outp["color_fine"], g["ren_color_fine"]) > 1e-3
+    with pytest.raises(NotImplementedError):       # per-ray near / far are refused loudly, never reduced to element 0
+        S["ren"].render(T(G["ro"]), T(G["rd"]), torch.linspace(0.1, 0.2, len(G["ro"])).to(S["dev"]), 1.0, S["sdf"], S["rnet"], lod=0,
+                        perturb_overwrite=0, conditional_volume=dense, conditional_valid_mask_volume=mask, feature_maps=T(G["fmaps"]),
+                        color_maps=T(sc["images"]), w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW],
+                        query_c2w=T(sc["query_c2w"])[None])
     R = G["cfg"]["grid_R"]
     v, t, u = S["ren"].extract_geometry(S["sdf"], torch.tensor([-1.0] * 3), torch.tensor([1.0] * 3), resolution=R, threshold=0, device=S["dev"],
                                         conditional_volume=dense, lod=0)
@@ -103,7 +119,7 @@ def test_vertex_colouring_like_trainer(S):
     assert rel(col.squeeze(0), g["vert_rgb"]) < 2e-4
 
 
-def test_mcubes_and_torchsparse_shims(S):
+def test_mcubes_shim(S):
     mcubes = importlib.import_module("one-2-3-45_amd.shims.mcubes")
     from oracle import mc as omc
     u = S["G"]["g"]["u"]
@@ -140,3 +156,80 @@ def test_lod1_coarse_to_fine_like_trainer(S):
     # a too-small budget triggers the (seeded, reproducible) subsampling instead of the reference's unseeded np.random.choice
     pc2, pf2 = S["ren"].get_valid_sparse_coords_by_sdf(T(g["l1_sdf_volume"])[None], lattice[0], mask[0], dense[0], threshold=0.004, maximum_pts=50)
     assert pc2.shape[0] <= 50 and pf2.shape == (pc2.shape[0], 16)
+
+
+def test_torchsparse_shim_forward_chain_vs_oracle():
+    """INTEGRATION.md's "shims only" level: a network written against the torchsparse API exactly the way tsparse/modules.py
+    does it (blocks = nn.Sequential(spnn.Conv3d, spnn.BatchNorm, spnn.ReLU(True)) under `.net`; U-Net wiring and state-dict keys of
+    SparseCostRegNet, modules.py:94-124, 259-304) runs on the HIP engine THROUGH shims/torchsparse (Conv3d.forward / BatchNorm.forward /
+    ReLU / SparseTensor.__add__) and equals oracle.sparse_costreg.  Also checks kernel-map reuse by the transposed convs, the
+    running-statistics update of BatchNorm and its eval-mode path."""
+    import torch.nn as nn
+    from oracle import recon as O
+    from scene_util import costreg_oracle_weights, small_scene
+    ts = importlib.import_module("one-2-3-45_amd.shims.torchsparse")
+    spnn = ts.nn
+    pkg = importlib.import_module("one-2-3-45_amd")
+    dev = torch.device("cuda:0")
+
+    class Block(nn.Module):
+        def __init__(self, inc, outc, stride=1, transposed=False):
+            super().__init__()
+            self.net = nn.Sequential(spnn.Conv3d(inc, outc, kernel_size=3, stride=stride, transposed=transposed), spnn.BatchNorm(outc), spnn.ReLU(True))
+
+        def forward(self, x):
+            return self.net(x)
+
+    class UNet(nn.Module):
+        def __init__(self, d_in, d_out):
+            super().__init__()
+            self.conv0 = Block(d_in, d_out)
+            self.conv1, self.conv2 = Block(d_out, 16, 2), Block(16, 16)
+            self.conv3, self.conv4 = Block(16, 32, 2), Block(32, 32)
+            self.conv5, self.conv6 = Block(32, 64, 2), Block(64, 64)
+            self.conv7, self.conv9, self.conv11 = Block(64, 32, 2, True), Block(32, 16, 2, True), Block(16, d_out, 2, True)
+
+        def forward(self, x):
+            c0 = self.conv0(x)
+            c2 = self.conv2(self.conv1(c0))
+            c4 = self.conv4(self.conv3(c2))
+            x = self.conv6(self.conv5(c4))
+            x = c4 + self.conv7(x)
+            x = c2 + self.conv9(x)
+            x = c0 + self.conv11(x)
+            return x.F
+
+    s = small_scene()
+    sd = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in s["costreg_sd"].items()}
+    net = UNet(32, 16).to(dev)
+    miss = net.load_state_dict(sd, strict=False)
+    assert not miss.unexpected_keys and all("running_" in k or "num_batches" in k for k in miss.missing_keys), miss
+    feat, coords = s["vol"].to(dev), s["coords"].to(dev)
+    x = ts.SparseTensor(feat, coords)
+    got = net(x)
+    want = s["rows16"]
+    assert rel(got, want.numpy()) < 1e-4
+    # coarse coordinate sets cached on the tensor = the oracle's levels, in the same order
+    for lv, key in zip(s["levels"][1:], (2, 4, 8)):
+        assert torch.equal(x.cmaps[key][0][:, :3].cpu().long(), lv.xyz)
+    # a single strided block and its values
+    w = costreg_oracle_weights(s["costreg_sd"])
+    c0 = O.bn_relu_rows(O.sparse_conv(s["vol"], O.build_kmap(s["levels"][0], s["levels"][0]), w["conv0"][0]), w["conv0"][1], w["conv0"][2])
+    y0 = net.conv0(ts.SparseTensor(feat, coords))
+    assert y0.s == 1 and rel(y0.F, c0.numpy()) < 1e-4
+    y1 = net.conv1(y0)
+    c1 = O.bn_relu_rows(O.sparse_conv(c0, O.build_kmap(s["levels"][0], s["levels"][1]), w["conv1"][0]), w["conv1"][1], w["conv1"][2])
+    assert y1.s == 2 and torch.equal(y1.C[:, :3].cpu().long(), s["levels"][1].xyz) and rel(y1.F, c1.numpy()) < 1e-4
+    # BatchNorm bookkeeping like nn.BatchNorm1d: running stats moved toward the batch stats, eval mode uses them
+    bn = net.conv0.net[1]
+    assert int(bn.num_batches_tracked) == 2 and float(bn.running_mean.abs().sum()) > 0
+    pre = O.sparse_conv(s["vol"], O.build_kmap(s["levels"][0], s["levels"][0]), w["conv0"][0])
+    ref_bn = torch.nn.BatchNorm1d(16)
+    ref_bn.weight.data, ref_bn.bias.data = w["conv0"][1].clone(), w["conv0"][2].clone()
+    ref_bn(pre); ref_bn(pre)
+    assert rel(bn.running_mean, ref_bn.running_mean.numpy()) < 1e-4 and rel(bn.running_var, ref_bn.running_var.numpy()) < 1e-4
+    net.eval(); ref_bn.eval()
+    ye = net.conv0(ts.SparseTensor(feat, coords))
+    assert rel(ye.F, torch.relu(ref_bn(pre)).detach().numpy()) < 1e-4
+    with pytest.raises(RuntimeError):
+        net.train()(ts.SparseTensor(feat.cpu(), coords.cpu()))            # HIP-only: no CPU fallback
