@@ -10,8 +10,17 @@ Inputs (images, cameras, weights) are resident in HBM before the timed region.  
 wall time of the K steps (whole step, i.e. including the volume build and the mesh extraction -- conservative);
 `render_rays_per_s` and `mesh_extract_ms` give the two halves of BASELINE's metric separately.
 
-N > 1: one process per GPU (torchrun), every rank reconstructs its own scene(s): embarrassingly parallel, no data-path
-collective -> "scaling": "weak".
+Every step reconstructs a DIFFERENT scene (seeded images; scene index = rank + world * step, the `scenes_for_rank` deal), so no
+step benefits from the previous step's L2 / MALL contents.
+
+N > 1: one process per GPU, every rank reconstructs its own scenes: embarrassingly parallel, no data-path collective
+-> "scaling": "weak".  `python bench.py --gpus N` works bare: when WORLD_SIZE is not set it re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (rendezvous on 127.0.0.1); under an existing torchrun launch it uses that.
+
+Besides the contract's line (config 2), rank 0 attaches: `parity_fullsize` (the cpu_baseline rays compared with the HIP outputs),
+`c3` (BASELINE config 3: 32 distinct scenes dealt over the ranks, inputs uploaded host->device inside the step), `ref_config`
+(the reference's own V=32 / 96^3 / 256^3 configuration), `config5` (256^3 volume, 1024^2 rays, 512^3 grid), `fp32_whole_step_ms`,
+`roofline_bf16_mode`, `cpu_baseline_reference` (the reference's own modules timed in the build container).  `--quick` skips them.
 """
 import argparse
 import importlib
@@ -71,19 +80,27 @@ class Timer:
         return float(np.mean(v)) if v else 0.0
 
 
+def scene_images(V, seed):
+    """The per-scene input: V source images [V,3,256,256] float32 (what Zero123 hands over), seeded."""
+    return np.random.default_rng(seed).random((V, 3, 256, 256), dtype=np.float32)
+
+
 def make_inputs(dev, V, seed, ray_scale):
+    """Camera rig / rays (identical for every scene of the rig, like the reference's fixed 8-view ring) + the images of scene `seed`."""
     sc = pkg.synth.make_scene(V, image_seed=seed)
+    assert np.array_equal(sc["images"], scene_images(V, seed))
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     ro, rd = pkg.synth.gen_rays(sc["query_intrinsic"], sc["query_c2w"], 256, 256, scale=ray_scale)
     proj, cam_pos = pipeline.camera_terms(T(sc["intrinsics"]), T(sc["w2cs"]))
     return dict(sc=sc, imgs=T(sc["images"]), aff=T(sc["affine_mats"]), origin=sc["partial_vol_origin"], rays_o=T(ro), rays_d=T(rd),
                 proj=proj, cam_pos=cam_pos, qcam=T(sc["query_c2w"][:3, 3].copy()), near=float(sc["query_near_far"][0]),
-                far=float(sc["query_near_far"][1]))
+                far=float(sc["query_near_far"][1]), ro_host=ro, rd_host=rd)
 
 
-def step(wt, inp, D, R_mesh, tm, chunk):
+def step(wt, inp, D, R_mesh, tm, chunk, imgs=None):
     vs = 2.0 / (D - 1)
-    tm.start("volume"); vol = pipeline.build_volume(wt, inp["imgs"], inp["aff"], inp["origin"], D, vs); tm.stop()
+    imgs = inp["imgs"] if imgs is None else imgs
+    tm.start("volume"); vol = pipeline.build_volume(wt, imgs, inp["aff"], inp["origin"], D, vs); tm.stop()
     tm.start("render")
     n = inp["rays_o"].shape[0]
     outs = []
@@ -169,10 +186,13 @@ def network_rooflines(kt, V, sdf_p, col_p):
     }
 
 
+PMC_FILE = "profiles/r02_pmc_f16x3.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_f16x3.json")) else "profiles/r01_pmc_f16x3.json"
+
+
 def pmc_traffic(kernel_prefix):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_f16x3.json; same workload,
-    separate FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_f16x3.json")
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (same workload, separate FETCH_SIZE / WRITE_SIZE runs;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  None if absent."""
+    path = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
@@ -182,30 +202,120 @@ def pmc_traffic(kernel_prefix):
     return None
 
 
-def cpu_baseline(wt, vol, inp, D, n_rays, budget_s=15.0):
-    """The oracle's render() (CPU restatement of the reference, oracle/recon.py) on a bounded sample of the same rays."""
-    from oracle import recon as O
-    torch.set_num_threads(min(32, os.cpu_count() or 1))      # more threads only add fork/join overhead on these op sizes
-    sc = inp["sc"]
-    dense = vol["vol_cl"].permute(3, 0, 1, 2).contiguous().cpu()
-    mask = vol["maskvol"].view(D, D, D).cpu()
-    W = {k: torch.from_numpy(np.asarray(v)) for k, v in wt.sdfW.items()}
-    RW = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in wt.color_sd.items()}
-    fm = vol["fmaps"].cpu()
+def cpu_baseline_and_parity(wt, vol, inp, D, n_rays, budget_s=15.0):
+    """cpu_baseline: the oracle's render() (CPU restatement of the reference, oracle/recon.py) on a bounded sample of the same rays.
+    parity_fullsize: the SAME oracle outputs compared with the HIP path on the same rays (both numerical forms), see tests/fullsize_util.py:
+    sampler stage with identical inputs, everything downstream on the HIP path's own sample lists (all rays), end-to-end distribution."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fullsize_util as FU                                     # test infrastructure (oracle side of the comparison)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))             # more threads only add fork/join overhead on these op sizes
+    dev = inp["imgs"].device
+    full = dict(wt=wt, sc=inp["sc"], vol=vol, proj=inp["proj"], cam_pos=inp["cam_pos"], D=D, ro=inp["ro_host"], rd=inp["rd_host"],
+                T=lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+    n = full["ro"].shape[0]
+    ref, sel, dt = FU.oracle_render_sample(full, n_rays, budget_s=budget_s)
+    cpu = {"value": len(sel) / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{len(sel)} of the {n} rays of the same scene (oracle.render, {FU.CHUNK}-ray chunks, fp32), {dt:.1f} s"}
+    par = {"rays": int(len(sel)), "oracle": "oracle/recon.py (pinned to the reference by tests/golden + tests/test_oracle_vs_reference.py)"}
+    sub = slice(0, min(len(sel), 512))                             # the downstream / stage checks re-run oracle stages: bounded subset
+    for prec in ("f16x3", "fp32"):
+        out = FU.gpu_render_sample(full, sel, prec)
+        cerr = (out["color"] - ref["color_fine"]).abs().max(1).values
+        derr = (out["depth"] - ref["depth"][:, 0]).abs()
+        core = FU.oracle_core_on(full, sel[sub], out["z_vals"][sub])
+        q = lambda t: [float(torch.quantile(t, x)) for x in (0.5, 0.9, 0.99)] + [float(t.max())]
+        par[prec] = {"color_err_q50_q90_q99_max": q(cerr), "depth_err_q50_q90_q99_max": q(derr),
+                     "frac_rays_color_gt_1e-4": float((cerr > 1e-4).float().mean()), "frac_rays_color_gt_1e-3": float((cerr > 1e-3).float().mean()),
+                     "color_mask_mismatches": int((out["color_mask"].bool() != ref["color_fine_mask"][:, 0]).sum()),
+                     "downstream_on_hip_samples": {"rays": int(core["depth"].shape[0]),
+                                                   "color_max": float((out["color"][sub] - core["color_fine"]).abs().max()),
+                                                   "depth_max": float((out["depth"][sub] - core["depth"][:, 0]).abs().max()),
+                                                   "weights_max": float((out["weights"][sub] - core["weights"]).abs().max())}}
+    ops_ = ops
+    s256 = sel[:256]
+    dz, pdf, width = FU.sampler_stage_check(ops_, dev, torch.from_numpy(full["ro"][s256]), torch.from_numpy(full["rd"][s256]), inp["near"], inp["far"],
+                                            FU._oracle_args(full), vol["maskvol"], D)
+    par["sampler_stage_identical_inputs"] = {"samples": int(dz.numel()), "dz_max": float(dz.max()), "dz_over_bin_width_max": float((dz / width.clamp(min=1e-9)).max())}
+    ce, _ = FU.oracle_self_sensitivity(full, s256, {k: v[:256] for k, v in ref.items()}, seeds=(1,))
+    par["oracle_self_sensitivity_to_2e-6_sdf_noise_color_q50_q90_q99_max"] = [float(torch.quantile(ce.flatten(), x)) for x in (0.5, 0.9, 0.99)] + [float(ce.max())]
+    return cpu, par
+
+
+def median_ms(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+def ref_config_block(dev, wt):
+    """The reference's own configuration (confs/one2345_lod0_val_demo.conf: 32 source views, 96^3 volume; export on a 256^3 grid): the
+    only published wall-clock for this path is export_mesh_step = 2.4887 s (example.ipynb:478, authors' GPU, incl. image decode + PLY write)."""
+    inp = make_inputs(dev, 32, 0, 1)
+    D, R = 96, 256
+    st = {}
+
+    def export():
+        st["vol"] = pipeline.build_volume(wt, inp["imgs"], inp["aff"], inp["origin"], D, 2.0 / (D - 1))
+        st["mesh"] = pipeline.extract_mesh(wt, st["vol"], inp["proj"], inp["cam_pos"], R)
+    t_export = median_ms(export)
+    t_val = median_ms(lambda: pipeline.render(wt, st["vol"], inp["proj"], inp["cam_pos"], inp["rays_o"], inp["rays_d"], inp["near"], inp["far"], inp["qcam"]), reps=3)
+    return {"workload": "V=32 views 256^2, 96^3 volume, 256^3 mesh grid (export_mesh_step body) + one 256x256 val image (64+64 samples)",
+            "export_mesh_ms_median": t_export, "val_image_ms_median": t_val, "val_rays_per_s": 65536 / (t_val * 1e-3),
+            "kept_voxels": int(st["vol"]["n_voxels"]), "vertices": int(st["mesh"][0].shape[0]), "triangles": int(st["mesh"][1].shape[0]),
+            "reference_published_export_mesh_s": 2.4887, "note": "random-weight stand-in scene: its surface (vertex count) is larger than a trained model's"}
+
+
+def config5_block(dev, wt, a):
+    """BASELINE config 5 shape: 256^3 sparse volume, 1024^2 rays, 512^3 mesh grid, one scene."""
+    inp = make_inputs(dev, a.views, 0, 4)
+    tm = Timer()
+    out = None
+    for _ in range(2):
+        out = None
+        out = step(wt, inp, 256, 512, tm, 1 << 20)
+    torch.cuda.synchronize(); tm.collect()
+    vol, outs, mesh = out
     n = inp["rays_o"].shape[0]
-    sel = torch.linspace(0, n - 1, n_rays).long()
-    ro, rd = inp["rays_o"].cpu()[sel], inp["rays_d"].cpu()[sel]
-    args = (torch.tensor(inp["near"]), torch.tensor(inp["far"]), dense, mask, W, RW, torch.tensor(0.2), fm, torch.from_numpy(sc["images"]),
-            torch.from_numpy(sc["w2cs"]), torch.from_numpy(sc["intrinsics"]), (256, 256), torch.from_numpy(sc["query_c2w"]))
-    done, t0 = 0, time.time()
-    with torch.no_grad():
-        while done < n_rays and time.time() - t0 < budget_s:      # bounded: stop after ~budget_s seconds of CPU work
-            O.render(ro[done:done + 16], rd[done:done + 16], *args)
-            done += 16
-    dt = time.time() - t0
-    n_rays = done
-    return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_rays} of the {n} rays of the same scene (oracle.render, 16-ray chunks, fp32), {dt:.1f} s"}
+    res = {"workload": f"{a.views} views 256^2, 256^3 volume, {n} rays, 512^3 mesh grid", "volume_build_ms": tm.acc["volume"][-1], "render_ms": tm.acc["render"][-1],
+           "mesh_extract_ms": tm.acc["mesh"][-1], "scene_ms": tm.acc["volume"][-1] + tm.acc["render"][-1] + tm.acc["mesh"][-1],
+           "render_rays_per_s": n / (tm.acc["render"][-1] * 1e-3), "kept_voxels": int(vol["n_voxels"]), "vertices": int(mesh[0].shape[0]),
+           "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9}
+    return res
+
+
+def c3_block(dev, wt, inp, a, rank, world):
+    """BASELINE config 3: 32 distinct scenes dealt over the ranks (scenes_for_rank: scene k on rank k mod world), each scene's images uploaded
+    host -> device INSIDE the step (pinned staging buffer, 6.3 MB), whole scene pass per scene."""
+    n_scenes = 32
+    mine = sharding.scenes_for_rank(n_scenes, rank, world)
+    host = [torch.from_numpy(scene_images(a.views, 1000 + k)).pin_memory() for k in mine]
+    tm = Timer()
+    out = step(wt, inp, a.vol, a.mesh_res, tm, a.ray_chunk)           # warm
+    out = None
+    sharding.barrier(dev)
+    t0 = time.perf_counter()
+    for h in host:
+        out = None
+        imgs = h.to(dev, non_blocking=True)
+        out = step(wt, inp, a.vol, a.mesh_res, tm, a.ray_chunk, imgs=imgs)
+    sharding.barrier(dev)
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    n_rays = inp["rays_o"].shape[0]
+    return {"workload": f"{n_scenes} distinct scenes, {len(mine)} per GPU on {world} GPU(s), images uploaded inside the step",
+            "scenes": n_scenes, "scenes_per_s": n_scenes / dt, "rays_per_s": n_scenes * n_rays / dt, "seconds": dt, "h2d_bytes_per_scene": int(host[0].numel() * 4)}
+
+
+def reexec_under_torchrun(n):
+    """`python bench.py --gpus N` invoked bare: start N ranks on this node (one per GPU) through torch.distributed.run."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -220,19 +330,47 @@ def main():
     ap.add_argument("--ray-chunk", type=int, default=1 << 18)
     ap.add_argument("--cpu-rays", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="only the contract's line (no c3 / ref_config / config5 / fp32 / bf16 blocks)")
+    ap.add_argument("--same-scene", action="store_true", help="re-reconstruct one scene every step (round-1 behaviour; A/B knob)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for the CPU plumbing test)")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous + sharding only, no GPU work (CPU plumbing test)")
     ap.add_argument("--precision", choices=config.PRECISIONS, default=config.PRECISION,
                     help="network kernels: f16x3 (default; split-f16 MFMA, fp32-class accuracy), fp32 (exact fp32 MFMA), bf16 (SDF throughput mode)")
     a = ap.parse_args()
-    rank, world, local = sharding.init()            # RCCL ("nccl") when WORLD_SIZE > 1; only used for the clock
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        reexec_under_torchrun(a.gpus)
+    rank, world, local = sharding.init(a.backend)            # RCCL ("nccl") when WORLD_SIZE > 1; only used for the clock
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)")
+    if a.dry_run:
+        # what the N > 1 path adds to the single-GPU path, without a GPU: rendezvous, scene deal, barrier, max-over-ranks clock, one line
+        mine = [rank + world * k for k in range(a.steps)]
+        sharding.barrier()
+        dt = sharding.max_over_ranks(0.01 * (rank + 1))
+        tot = sharding.sum_over_ranks(len(mine))
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": a.steps, "scenes_total": tot, "slowest_rank_s": dt, "rank0_scenes": mine}))
+        sharding.shutdown()
+        return
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the reconstruction path has no CPU fallback)"
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} device(s) are visible")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if world > 1:                                            # every rank on its own GPU
+        ids = [None] * world
+        torch.distributed.all_gather_object(ids, (os.uname().nodename, local))
+        assert len(set(ids)) == world, f"ranks share a device: {ids}"
     wt = pipeline.SceneWeights(dev, seed=0, sdf_precision=a.precision, color_precision=a.precision)
     inp = make_inputs(dev, a.views, seed=rank, ray_scale=a.ray_scale)
+    # distinct scene per step: scene index = rank + world * step (images resident in HBM before the timed region starts)
+    n_total = a.warmup + a.steps
+    scene_imgs = [inp["imgs"] if a.same_scene else torch.from_numpy(scene_images(a.views, rank + world * k)).to(dev) for k in range(n_total)]
     tm = Timer()
     vol = outs = mesh = None
-    for _ in range(a.warmup):
+    for k in range(a.warmup):
         vol = outs = mesh = None                 # release the previous scene's outputs first: every step then reuses the same
-        vol, outs, mesh = step(wt, inp, a.vol, a.mesh_res, tm, a.ray_chunk)      # cached blocks (no hipMalloc inside a timed step)
+        vol, outs, mesh = step(wt, inp, a.vol, a.mesh_res, tm, a.ray_chunk, imgs=scene_imgs[k])      # cached blocks (no hipMalloc inside a timed step)
     tm.collect(); tm.acc = {}
 
     # a full (generation-2) Python GC pass over the ~10^6 objects that `import torch` creates takes 30-40 ms and would land
@@ -243,9 +381,9 @@ def main():
     sharding.barrier(dev)
     t0 = time.perf_counter()
     alloc_log = []
-    for _ in range(a.steps):
+    for k in range(a.steps):
         vol = outs = mesh = None
-        vol, outs, mesh = step(wt, inp, a.vol, a.mesh_res, tm, a.ray_chunk)
+        vol, outs, mesh = step(wt, inp, a.vol, a.mesh_res, tm, a.ray_chunk, imgs=scene_imgs[a.warmup + k])
         if os.environ.get("O2345_BENCH_VERBOSE"):
             st = torch.cuda.memory_stats()
             alloc_log.append((st["num_device_alloc"], st["num_device_free"], round((time.perf_counter() - t0) * 1e3, 1)))
@@ -259,6 +397,10 @@ def main():
         print({k: st[k] for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "reserved_bytes.all.peak", "allocated_bytes.all.peak")}, file=sys.stderr)
     n_rays = inp["rays_o"].shape[0]
     ms_step = dt / a.steps * 1e3
+    c3 = None
+    if not a.quick:
+        scene_imgs = None
+        c3 = c3_block(dev, wt, inp, a, rank, world)          # all ranks take part (barrier + max-over-ranks clock inside)
     result = None
     if rank == 0:
         kt = kernel_times(wt, vol, inp, outs, a.vol)
@@ -273,7 +415,8 @@ def main():
             "metric": "rays/sec + mesh-extract wall-clock per scene (8x256^2 views, 128^3 vol)", "value": world * n_rays / (ms_step * 1e-3),
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2: 1 scene/GPU/step, {a.views} views 256x256, {a.vol}^3 volume, "
+            "config": {"workload": f"BASELINE config 2: 1 scene/GPU/step ({'the same scene' if a.same_scene else 'a different seeded scene'} every step), "
+                                   f"{a.views} views 256x256, {a.vol}^3 volume, "
                                    f"{n_rays} rays (64+64 samples), mesh grid {a.mesh_res}^3; whole scene pass per step",
                        "views": a.views, "volume": a.vol, "rays": n_rays, "mesh_res": a.mesh_res, "parallelism": f"scenes x{world}",
                        "precision": a.precision},
@@ -284,18 +427,40 @@ def main():
             # dominant kernel of a step = the colour network: ALGORITHMIC FLOP (38,544 per (point, view)) x occupied
             # points x views / HIP-event time of that launch, against the dense MFMA peak of the type the matrix pipe runs in
             "roofline": dict(rl["color"], traffic=pmc_traffic("k_color_mfma"),
-                             traffic_source="profiles/r01_pmc_f16x3.json (bytes, 2*FETCH_SIZE+WRITE_SIZE)"),
+                             traffic_source=PMC_FILE + " (bytes, 2*FETCH_SIZE+WRITE_SIZE)"),
             "roofline_sdf": rl["sdf"], "roofline_sdf_grad": rl["sdf_grad"],
             "roofline_costvol": {"kernel": "k_costvol_gather<16>", "bound": "hbm", "achieved": cv_bytes / (kt["costvol_gather_ms"] * 1e-3) / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cv_bytes / (kt["costvol_gather_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": pmc_traffic("k_costvol_gather"), "algorithmic_bytes": cv_bytes, "ms": kt["costvol_gather_ms"]},
         }
+        if c3 is not None:
+            result["c3"] = c3
         if a.precision != "fp32":
             # the same three kernels in the exact fp32 MFMA form, priced against the fp32 matrix peak (strict mode of the library)
             kf = kernel_times(wt, vol, inp, outs, a.vol, reps=3, sdf_precision="fp32", color_precision="fp32")
             result["roofline_fp32_mode"] = network_rooflines(kf, V, "fp32", "fp32")
+        if a.precision != "bf16" and not a.quick:
+            # BASELINE config 2's wording ("bf16 SDF MLP"): the SDF kernels in the bf16 throughput mode (opt-in: 3e-3 SDF error)
+            kb = kernel_times(wt, vol, inp, outs, a.vol, reps=3, sdf_precision="bf16", color_precision="f16x3")
+            rb = network_rooflines(kb, V, "bf16", "f16x3")
+            result["roofline_bf16_mode"] = {"sdf": rb["sdf"], "sdf_grad": rb["sdf_grad"]}
         if world == 1 and not a.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(wt, vol, inp, a.vol, a.cpu_rays)
+            vol0 = pipeline.build_volume(wt, inp["imgs"], inp["aff"], inp["origin"], a.vol, 2.0 / (a.vol - 1))     # the scene cpu_baseline's images belong to
+            result["cpu_baseline"], result["parity_fullsize"] = cpu_baseline_and_parity(wt, vol0, inp, a.vol, a.cpu_rays)
+            ref_file = os.path.join(ROOT, "profiles", "r02_cpu_reference.json")
+            if os.path.exists(ref_file):
+                result["cpu_baseline_reference"] = json.load(open(ref_file))
+            vol0 = None
+        if world == 1 and not a.quick:
+            vol = outs = mesh = None
+            if a.precision != "fp32":
+                wf = pipeline.SceneWeights(dev, seed=0, sdf_precision="fp32", color_precision="fp32")
+                tf = Timer()
+                result["fp32_whole_step_ms"] = median_ms(lambda: step(wf, inp, a.vol, a.mesh_res, tf, a.ray_chunk), reps=3)
+                wf = None
+            result["ref_config"] = ref_config_block(dev, wt)
+            torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+            result["config5"] = config5_block(dev, wt, a)
         print(json.dumps(result))
     sharding.shutdown()
 

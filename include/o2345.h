@@ -187,12 +187,12 @@ int o2345_color_points_x3(const float* blob, const float* vol_cl, const float* m
                           const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
 
 /* ---- marching cubes (replaces mcubes.marching_cubes, call site models/sparse_neus_renderer.py:932) -----------------
- * u [n0,n1,n2] float32 on the device.  count() synchronises the stream and returns the sizes on the host;
+ * u [n0,n1,n2] float32 on the device; iso is a DOUBLE like PyMCubes' isovalue (ABI 1.2).  count() synchronises the stream and returns the sizes on the host;
  * emit() writes verts float64 [nv,3] (index coordinates) and tris int32/int64 [nt,3]. */
 size_t o2345_mc_workspace_bytes(int n0, int n1, int n2);
-int o2345_marching_cubes_count(const float* u, int n0, int n1, int n2, float iso, void* workspace,
+int o2345_marching_cubes_count(const float* u, int n0, int n1, int n2, double iso, void* workspace,
                                size_t workspace_bytes, long long* nv_host, long long* nt_host, void* stream);
-int o2345_marching_cubes_emit(const float* u, int n0, int n1, int n2, float iso, void* workspace, double* verts,
+int o2345_marching_cubes_emit(const float* u, int n0, int n1, int n2, double iso, void* workspace, double* verts,
                               void* tris, int index_bytes, void* stream);
 
 /* ---- mesh serialisation (replaces the numpy / trimesh tail of validate_mesh and validate_colored_mesh,

@@ -7,6 +7,7 @@
 // cell in traversal order, table order inside a cell.  Deterministic: counts -> exclusive scans -> emit, no atomics.
 // Everything stays on the device; u (67 MB at 256^3) is read three times, HBM-bound.
 #include "common.h"
+#include <math.h>
 #include "mc_tables.h"
 
 namespace o2345 {
@@ -21,8 +22,16 @@ constexpr int MC_TILE = 256 * MC_ITEMS;     // per block
 struct McGrid {
     int n0, n1, n2;
     long long s0, s1, n;
-    float iso;
+    float iso;        // classification threshold: the largest float <= iso_d, so that  u <= iso  <=>  (double)u <= iso_d  for every float u
+    double iso_d;     // PyMCubes takes a DOUBLE isovalue: interpolation uses it unrounded
 };
+
+// host: McGrid for a double isovalue
+static McGrid mc_grid(int n0, int n1, int n2, double iso) {
+    float f = (float)iso;
+    if ((double)f > iso) f = nextafterf(f, -INFINITY);
+    return McGrid{n0, n1, n2, (long long)n1 * n2, (long long)n2, (long long)n0 * n1 * n2, f, iso};
+}
 
 __device__ __forceinline__ void mc_point_counts(const float* __restrict__ u, const McGrid& g, long long p, int& nv, int& nt) {
     const int z = (int)(p % g.n2), y = (int)((p / g.n2) % g.n1), x = (int)(p / g.s0);
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(256) void k_mc_verts(const float* __restrict__ u, M
     if (p >= g.n || vcnt[p] == 0) return;
     const int c[3] = {(int)(p / g.s0), (int)((p / g.n2) % g.n1), (int)(p % g.n2)};
     const long long back[3] = {g.s0, g.s1, 1};
-    const double f1 = (double)u[p], iso = (double)g.iso;
+    const double f1 = (double)u[p], iso = g.iso_d;
     long long id = vbase[p];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -207,7 +216,7 @@ static void mc_carve(void* ws, size_t n, uint8_t*& vcnt, uint16_t*& tcase, int*&
 
 // Pass 1 of the two-call protocol: classifies, scans, and returns the vertex / triangle counts on the HOST
 // (synchronises the stream once -- the caller must allocate the outputs).
-int o2345_marching_cubes_count(const float* u, int n0, int n1, int n2, float iso, void* workspace, size_t workspace_bytes,
+int o2345_marching_cubes_count(const float* u, int n0, int n1, int n2, double iso, void* workspace, size_t workspace_bytes,
                                long long* nv_host, long long* nt_host, void* stream) {
     O2345_REQUIRE(u && workspace && nv_host && nt_host, "marching_cubes_count: null pointer");
     O2345_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "marching_cubes_count: grid must be at least 2^3");
@@ -216,7 +225,7 @@ int o2345_marching_cubes_count(const float* u, int n0, int n1, int n2, float iso
     O2345_REQUIRE(n < (1ull << 31), "marching_cubes_count: grid too large");
     uint8_t* vcnt; uint16_t* tcase; int *vbase, *tbase, *vblock, *tblock; long long* totals;
     mc_carve(workspace, n, vcnt, tcase, vbase, tbase, vblock, tblock, totals);
-    McGrid g{n0, n1, n2, (long long)n1 * n2, (long long)n2, (long long)n, iso};
+    const McGrid g = mc_grid(n0, n1, n2, iso);
     const unsigned nb = (unsigned)((n + MC_TILE - 1) / MC_TILE);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_mc_count, dim3(nb), dim3(256), 0, s, u, g, vcnt, tcase, vblock, tblock);
@@ -234,14 +243,14 @@ int o2345_marching_cubes_count(const float* u, int n0, int n1, int n2, float iso
 }
 
 // Pass 2: emit.  verts float64 [nv,3]; tris int32 or int64 [nt,3] (index_bytes = 4 or 8).  Same workspace as pass 1.
-int o2345_marching_cubes_emit(const float* u, int n0, int n1, int n2, float iso, void* workspace, double* verts, void* tris,
+int o2345_marching_cubes_emit(const float* u, int n0, int n1, int n2, double iso, void* workspace, double* verts, void* tris,
                               int index_bytes, void* stream) {
     O2345_REQUIRE(u && workspace, "marching_cubes_emit: null pointer");
     O2345_REQUIRE(index_bytes == 4 || index_bytes == 8, "marching_cubes_emit: index_bytes must be 4 or 8");
     const size_t n = (size_t)n0 * n1 * n2;
     uint8_t* vcnt; uint16_t* tcase; int *vbase, *tbase, *vblock, *tblock; long long* totals;
     mc_carve(workspace, n, vcnt, tcase, vbase, tbase, vblock, tblock, totals);
-    McGrid g{n0, n1, n2, (long long)n1 * n2, (long long)n2, (long long)n, iso};
+    const McGrid g = mc_grid(n0, n1, n2, iso);
     hipStream_t s = (hipStream_t)stream;
     if (verts) hipLaunchKernelGGL(k_mc_verts, dim3(cdiv(n, 256)), dim3(256), 0, s, u, g, vcnt, vbase, verts);
     if (tris) {

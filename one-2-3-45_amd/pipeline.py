@@ -41,6 +41,7 @@ class SceneWeights:
         self.color_mblob = t(weights.pack_color_mfma_blob(self.color_sd))
         self.color_xblob = t(weights.pack_color_x3_blob(self.color_sd))
         self.costreg = CostRegNet(self.costreg_sd, device, precision=color_precision)      # sparse convolutions follow the same mode
+        self.variance = float(variance)
         self.inv_s = float(np.clip(np.exp(10.0 * variance), 1e-6, 1e6))
 
     @classmethod

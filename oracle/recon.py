@@ -317,10 +317,18 @@ def sdf_mlp(pts, latent, W):
     return torch.cat([h, latent], 1) @ W["w2"].T + W["b2"]
 
 
+SDF_NOISE = None      # (relative sigma, torch.Generator) or None.  Sensitivity probe ONLY (tests/fullsize_util.py): multiplies the SDF
+                      # output by (1 + sigma * N(0,1)) to measure how the hierarchical sampler amplifies fp32-class SDF differences.
+
+
 def sdf(pts, volume, W):
     """SparseSdfNetwork.sdf (sparse_sdf_network.py:402-420): volume [C,D,D,D] -> (y[P,128], latent[P,16])."""
     lat = trilinear_ref(volume, pts)
-    return sdf_mlp(pts, lat, W), lat
+    y = sdf_mlp(pts, lat, W)
+    if SDF_NOISE is not None:
+        sigma, gen = SDF_NOISE
+        y = torch.cat([y[:, :1] * (1 + sigma * torch.randn(y.shape[0], 1, generator=gen)), y[:, 1:]], 1)
+    return y, lat
 
 
 def sdf_grad(pts, volume, W):
@@ -348,34 +356,19 @@ def sdf_grad(pts, volume, W):
 # ----------------------------------------------------------------------------------------------
 # a17, a19: hierarchical sampling (sparse_neus_renderer.py:73-151, render_utils.py:8-51)
 # ----------------------------------------------------------------------------------------------
-CUMSUM_FP32_SEQUENTIAL = False   # ATen's CPU cumsum accumulates fp32 rows in DOUBLE; CUDA/HIP kernels accumulate in fp32.
-                                 # Samples falling in empty bins (pdf = 1e-5/sum) amplify that 1e-7 difference by ~1e5.
-
-
-def _cumsum(pdf):
-    if not CUMSUM_FP32_SEQUENTIAL:
-        return torch.cumsum(pdf, -1)
-    out, run = torch.empty_like(pdf), torch.zeros_like(pdf[:, 0])
-    for k in range(pdf.shape[1]):
-        run = run + pdf[:, k]
-        out[:, k] = run
-    return out
-
-
-def sample_pdf_det(bins, weights, n):
+def sample_pdf_det(bins, weights, n, diag=None):
+    """diag (list or None): receives, per call, the pdf mass [R,n] of the bin every new sample lands in.  A sample in a
+    bin of mass p is placed with a sensitivity of (bin width / p) to the cdf: p ~ 1e-5 ("empty" bin of a ray that hits the
+    surface) amplifies fp32 rounding in the cdf (1e-7) to ~1 % of a bin -- the conditioning measure used by the full-size test."""
     w = weights + 1e-5
-    if CUMSUM_FP32_SEQUENTIAL:
-        ws = torch.zeros_like(w[:, 0])
-        for k in range(w.shape[1]):
-            ws = ws + w[:, k]
-        pdf = w / ws[:, None]
-    else:
-        pdf = w / w.sum(-1, keepdim=True)
-    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), _cumsum(pdf)], -1)
+    pdf = w / w.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
     u = torch.linspace(0.5 / n, 1 - 0.5 / n, n).expand(cdf.shape[0], n).contiguous()
     ind = torch.searchsorted(cdf, u, right=True)
     lo = (ind - 1).clamp(min=0)
     hi = ind.clamp(max=cdf.shape[1] - 1)
+    if diag is not None:
+        diag.append(pdf.gather(1, lo.clamp(max=pdf.shape[1] - 1)))          # [R,n]: pdf mass of the bin each new sample lands in
     c0, c1 = cdf.gather(1, lo), cdf.gather(1, hi)
     b0, b1 = bins.gather(1, lo), bins.gather(1, hi)
     den = c1 - c0
@@ -383,7 +376,7 @@ def sample_pdf_det(bins, weights, n):
     return b0 + (u - c0) / den * (b1 - b0)
 
 
-def up_sample(rays_o, rays_d, z, sdf_v, n_imp, inv_s, maskvol):
+def up_sample(rays_o, rays_d, z, sdf_v, n_imp, inv_s, maskvol, diag=None):
     pts = rays_o[:, None] + rays_d[:, None] * z[..., None]
     m = mask_nearest(maskvol, pts.reshape(-1, 3)).reshape(z.shape)
     m = m[:, :-1] * m[:, 1:]
@@ -397,7 +390,7 @@ def up_sample(rays_o, rays_d, z, sdf_v, n_imp, inv_s, maskvol):
     nc = torch.sigmoid((mid + dot * dist * 0.5) * inv_s)
     alpha = m * ((pc - nc + 1e-5) / (pc + 1e-5))
     T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-7], 1), 1)[:, :-1]
-    return sample_pdf_det(z, alpha * T, n_imp)
+    return sample_pdf_det(z, alpha * T, n_imp, diag)
 
 
 def cat_z(rays_o, rays_d, z, new_z, sdf_v, volume, maskvol, W):
@@ -496,8 +489,10 @@ def rendering_network(RW, geo, rgb_feat, rdiff, mask):
 # a16, a21: render / render_core (sparse_neus_renderer.py:171-635), general rendering; perturb > 0 when t_rand is given
 # ----------------------------------------------------------------------------------------------
 def render(rays_o, rays_d, near, far, volume, maskvol, W, RW, variance, feat_maps, color_maps, w2cs, K, img_wh,
-           query_c2w, n_samples=64, n_importance=64, alpha_inter_ratio=1.0, background_rgb=1.0, t_rand=None):
-    """t_rand [R, n_samples]: the stratified jitter of :506-515 (the reference draws torch.rand(z_vals.shape) on the host)."""
+           query_c2w, n_samples=64, n_importance=64, alpha_inter_ratio=1.0, background_rgb=1.0, t_rand=None, diag=None, trace=None):
+    """t_rand [R, n_samples]: the stratified jitter of :506-515 (the reference draws torch.rand(z_vals.shape) on the host).
+    diag: see sample_pdf_det.  trace (list or None): receives per up-sampling round the sampler's input state and output
+    dict(z [R,S], sdf [R,S], inv_s, new_z [R,n]) -- lets a test drive the HIP sampler stage with IDENTICAL inputs."""
     R = rays_o.shape[0]
     sample_dist = float((far - near) / n_samples)
     z = (near + (far - near) * torch.linspace(0, 1, n_samples))[None].repeat(R, 1)
@@ -509,8 +504,19 @@ def render(rays_o, rays_d, near, far, volume, maskvol, W, RW, variance, feat_map
     pts = (rays_o[:, None] + rays_d[:, None] * z[..., None]).reshape(-1, 3)
     s = sdf(pts, volume, W)[0][:, 0].reshape(R, n_samples)     # coarse pass is NOT masked (:525-528)
     for i in range(4):
-        nz = up_sample(rays_o, rays_d, z, s, n_importance // 4, 64.0 * 2 ** i, maskvol)
+        nz = up_sample(rays_o, rays_d, z, s, n_importance // 4, 64.0 * 2 ** i, maskvol, diag)
+        if trace is not None:
+            trace.append(dict(z=z.clone(), sdf=s.clone(), inv_s=64.0 * 2 ** i, new_z=nz.clone()))
         z, s = cat_z(rays_o, rays_d, z, nz, s, volume, maskvol, W)
+    return render_core(rays_o, rays_d, z, sample_dist, volume, maskvol, W, RW, variance, feat_maps, color_maps, w2cs, K, img_wh,
+                       query_c2w, alpha_inter_ratio, background_rgb)
+
+
+def render_core(rays_o, rays_d, z, sample_dist, volume, maskvol, W, RW, variance, feat_maps, color_maps, w2cs, K, img_wh, query_c2w,
+                alpha_inter_ratio=1.0, background_rgb=1.0):
+    """Everything of render() after the hierarchical sampling (sparse_neus_renderer.py:555-635 + render_core :171-455) for GIVEN
+    sorted sample depths z [R,S]."""
+    R = rays_o.shape[0]
     S = z.shape[1]
     dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((R, 1), sample_dist)], 1)
     mid = z + dists * 0.5

@@ -47,3 +47,26 @@ def test_single_process_is_a_noop():
     sh = importlib.import_module("one-2-3-45_amd.sharding")
     assert sh.scenes_for_rank(5, 0, 1) == [0, 1, 2, 3, 4]
     assert sh.max_over_ranks(3.5) == 3.5 and sh.sum_over_ranks(2) == 2.0
+
+
+def test_bench_bare_invocation_spawns_ranks():
+    """`python bench.py --gpus 2` invoked BARE (no torchrun, no WORLD_SIZE): bench.py re-executes itself under
+    torch.distributed.run with 2 ranks, every rank is dealt different scenes, rank 0 prints ONE json line with n_gpus = 2.
+    (--dry-run --backend gloo: the rendezvous / deal / clock plumbing without GPUs.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scenes_total"] == 6.0 and d["rank0_scenes"] == [0, 2, 4] and d["slowest_rank_s"] == 0.02
+    # a launcher / flag mismatch is refused instead of silently measuring fewer GPUs
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"],
+                        capture_output=True, text=True, timeout=120, env=env2, cwd=root)
+    assert r2.returncode != 0 and "--gpus 2" in (r2.stderr + r2.stdout)

@@ -1,0 +1,67 @@
+"""Times the REFERENCE's own modules (imported from /root/reference, CPU, stubs per oracle/ref_import.py) on BASELINE config-2 inputs:
+SparseNeuSRenderer.render (512-ray chunks, like the runner) and extract_fields.  Build container only (the GPU box has no
+/root/reference); writes profiles/r02_cpu_reference.json, which bench.py attaches as `cpu_baseline_reference`.
+
+    python tools/time_reference_cpu.py [seconds]"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import recon as O  # noqa: E402
+from oracle import ref_import as RI  # noqa: E402
+
+pkg = importlib.import_module("one-2-3-45_amd")
+
+
+@torch.no_grad()
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+    V, HW, D = 8, 256, 128
+    sc = pkg.synth.make_scene(V, image_seed=0)
+    sdfnet, rnet, var, renderer = RI.build_networks(D, seed=0)
+    T = torch.from_numpy
+    rng = np.random.default_rng(0)
+    # geometry of the real scene (which voxels are valid) from the visibility count; latents random -- the timing does not depend on them
+    feats16 = T(rng.standard_normal((V, 1, HW, HW)).astype(np.float32))
+    coords, _, _ = O.costvol(feats16, T(sc["affine_mats"]), [D, D, D], 2.0 / (D - 1), T(sc["partial_vol_origin"]))
+    mask = torch.zeros(D, D, D)
+    mask[coords[:, 0].long(), coords[:, 1].long(), coords[:, 2].long()] = 1
+    dense = (torch.from_numpy(rng.standard_normal((16, D, D, D)).astype(np.float32)) * 0.1 * mask[None])[None]
+    mask = mask[None, None]
+    fmaps = T(rng.standard_normal((V, 56, HW, HW)).astype(np.float32))
+    ro, rd = pkg.synth.gen_rays(sc["query_intrinsic"], sc["query_c2w"], 256, 256, scale=2)
+    near, far = T(sc["query_near_far"][:1]), T(sc["query_near_far"][1:])
+    sel = np.linspace(0, len(ro) - 1, 1 << 14).astype(np.int64)
+    done, t0 = 0, time.time()
+    while time.time() - t0 < budget and done + 512 <= len(sel):
+        s = sel[done:done + 512]
+        renderer.render(T(ro[s]), T(rd[s]), near, far, sdfnet, rnet, perturb_overwrite=0, background_rgb=1.0, alpha_inter_ratio=1.0, lod=0,
+                        conditional_volume=dense, conditional_valid_mask_volume=mask, feature_maps=fmaps, color_maps=T(sc["images"]),
+                        w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW], query_c2w=T(sc["query_c2w"])[None],
+                        if_render_with_grad=False)
+        done += 512
+    dt = time.time() - t0
+    R = 64
+    t1 = time.time()
+    renderer.extract_fields(torch.tensor([-1.0] * 3), torch.tensor([1.0] * 3), R, lambda p, **kw: sdfnet.sdf(p, **kw), "cpu",
+                            conditional_volume=dense, lod=0)
+    de = time.time() - t1
+    out = {"what": "the reference's own SparseNeuSRenderer.render / extract_fields (models/sparse_neus_renderer.py:457-635, 881-905) on CPU, "
+                   "BASELINE config-2 inputs (8 views 256^2, 128^3 volume), measured in the BUILD CONTAINER (not on the GPU box)",
+           "value": done / dt, "unit": "rays/s", "cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "kind": "reference",
+           "sample": f"{done} rays in 512-ray chunks (the runner's batch size), {dt:.1f} s",
+           "extract_fields_points_per_s": R ** 3 / de, "extract_fields_sample": f"{R}^3 grid, {de:.1f} s (a 256^3 grid is 64x that)"}
+    path = os.path.join(ROOT, "profiles", "r02_cpu_reference.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
