@@ -41,7 +41,7 @@ constexpr int CM_A_V1 = CM_A_V0 + 16 * 64;          // [1][16][64]  (rows 0..31 
 constexpr int CM_A_V20 = CM_A_V1 + 16 * 64;         // [1][16][64]
 constexpr int CM_A_R0 = CM_A_V20 + 16 * 64;         // [1][19][64]
 constexpr int CM_A_R1 = CM_A_R0 + 19 * 64;          // [1][8][64]
-constexpr int CM_BIAS0 = CM_A_R1 + 8 * 64;          // biases / per-lane vectors, [block][16][2] each
+constexpr int CM_BIAS0 = CM_A_R1 + 8 * 64;          // biases / per-lane vectors, [block][half][16] each
 constexpr int CM_B_RD0 = CM_BIAS0, CM_B_RD1 = CM_B_RD0 + 32, CM_B_B0 = CM_B_RD1 + 64, CM_B_B1 = CM_B_B0 + 64,
               CM_B_V0 = CM_B_B1 + 32, CM_B_V1 = CM_B_V0 + 32, CM_B_V20 = CM_B_V1 + 32, CM_B_R0 = CM_B_V20 + 32,
               CM_B_R1 = CM_B_R0 + 32, CM_V_V1X = CM_B_R1 + 32, CM_V_V21 = CM_V_V1X + 32, CM_V_R2 = CM_V_V21 + 32;
@@ -163,12 +163,18 @@ __device__ __forceinline__ void cm_layer(f32x16 (&acc)[NB], const float* lds, in
     else cm_run<NB, N, N>(acc, lds + lane + off32, 0, b);
 }
 
+// biases are stored [block][half][16 registers]: four 16-byte LDS reads straight into the accumulator tuple
 template <int NB>
 __device__ __forceinline__ void cm_bias(f32x16 (&acc)[NB], const float* bias, int h) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NB; ++nb) {
+        const float4* p = reinterpret_cast<const float4*>(bias + (nb * 2 + h) * 16);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = bias[(nb * 16 + r) * 2 + h];
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = p[q];
+            acc[nb][4 * q] = t.x; acc[nb][4 * q + 1] = t.y; acc[nb][4 * q + 2] = t.z; acc[nb][4 * q + 3] = t.w;
+        }
+    }
 }
 
 // Reductions over the G view lanes of a point (G consecutive lanes, G | 32) with DPP lane permutes instead of
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(768) void k_color_mfma(ColorMArgs a) {
             cm_layer<X3, 1, 16>(t2, lds, lane, CM_A_V1, CX_A_V1, bin, m1);
             float vr = 0.f;                                           // output 32 of vis_fc.2: dot product over both halves
 #pragma unroll
-            for (int r = 0; r < 16; ++r) vr = fmaf(bin[r], lds[TAIL + CM_V_V1X + r * 2 + h], vr);
+            for (int r = 0; r < 16; ++r) vr = fmaf(bin[r], lds[TAIL + CM_V_V1X + h * 16 + r], vr);
             vr += __shfl_xor(vr, 32);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) { const f32x2 e2 = celu2(t2[0][r], t2[0][r + 1]); x32[0][r] += e2[0]; x32[0][r + 1] += e2[1]; }
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(768) void k_color_mfma(ColorMArgs a) {
             for (int r = 0; r < 16; r += 2) { const f32x2 e2 = celu2(t1[0][r], t1[0][r + 1]); bin[r] = e2[0]; bin[r + 1] = e2[1]; }
             float vr = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) vr = fmaf(bin[r], lds[TAIL + CM_V_V21 + r * 2 + h], vr);
+            for (int r = 0; r < 16; ++r) vr = fmaf(bin[r], lds[TAIL + CM_V_V21 + h * 16 + r], vr);
             vr += __shfl_xor(vr, 32);
             vis = csigm(vr + lds[TAIL + CM_S + 2]) * m;
         }
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(768) void k_color_mfma(ColorMArgs a) {
             for (int r = 0; r < 4; r += 2) { const f32x2 e2 = celu2(t2[0][r], t2[0][r + 1]); r8[r] = e2[0]; r8[r + 1] = e2[1]; }
             float sr = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sr = fmaf(r8[r], lds[TAIL + CM_V_R2 + r * 2 + h], sr);
+            for (int r = 0; r < 4; ++r) sr = fmaf(r8[r], lds[TAIL + CM_V_R2 + h * 16 + r], sr);
             score = sr + __shfl_xor(sr, 32) + lds[TAIL + CM_S + 3];
         }
         // ---- masked softmax over views, blended colour ----------------------------------------------------------------------------------

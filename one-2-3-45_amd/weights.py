@@ -558,7 +558,7 @@ def init_costreg_state_dict(seed=0, d_in=32):
 # A wave owns 32 (point, view) columns; both wave halves hold the same column and supply the two k rows of each
 # 32x32x2 step.  Pixel floats (rgb 3 | feat 56 | pad 5 = 64) are split 32|32 between the halves.
 # single-output layers (vis_fc.2 row 32, vis_fc2.2, rgb_fc.4) are per-lane dot products over the lane's registers (V_* vectors in
-# the same [16][2] lane-half order as the biases) + one cross-half add: a 32-row MFMA block for one output would waste 36 MFMAs
+# the same [2][16] half-major order as the biases) + one cross-half add: a 32-row MFMA block for one output would waste 36 MFMAs
 CM_SEGS = [("A_RD0", 1, 2), ("A_RD1", 2, 8), ("A_B0", 2, 32), ("A_B1", 1, 32), ("A_V0", 1, 16), ("A_V1", 1, 16),
            ("A_V20", 1, 16), ("A_R0", 1, 19), ("A_R1", 1, 8)]
 CM_BIAS = [("B_RD0", 1), ("B_RD1", 2), ("B_B0", 2), ("B_B1", 1), ("B_V0", 1), ("B_V1", 1), ("B_V20", 1),
@@ -603,13 +603,13 @@ def pack_color_mfma_blob(sd):
 
     def bias(name, bvec, out_of_row):
         off, nb, _ = CM_LAYOUT[name]
-        a = blob[off:off + nb * 32].reshape(nb, 16, 2)
+        a = blob[off:off + nb * 32].reshape(nb, 2, 16)              # [block][half][register]: one 64-byte vector per (block, half)
         for b in range(nb):
             for r in range(16):
                 for h in (0, 1):
                     o = out_of_row(b, neuron_of(0, r, h))
                     if o is not None and o < bvec.shape[0]:
-                        a[b, r, h] = bvec[o]
+                        a[b, h, r] = bvec[o]
 
     plain = lambda b, i: b * 32 + i
     # rd1 output rows are permuted so that a lane receives the direction feature of ITS pixel floats: row i of block b
@@ -638,12 +638,12 @@ def pack_color_mfma_blob(sd):
     def vec(name, wrow, n_in):
         """per-lane weights of a single-output layer: slot (r, h) holds wrow[neuron_of(0, r, h)] (inputs = registers of block 0)"""
         off, _, _ = CM_LAYOUT[name]
-        a = blob[off:off + 32].reshape(16, 2)
+        a = blob[off:off + 32].reshape(2, 16)
         for r in range(16):
             for h in (0, 1):
                 n = neuron_of(0, r, h)
                 if n < n_in:
-                    a[r, h] = wrow[n]
+                    a[h, r] = wrow[n]
     vec("V_V1X", g("vis_fc.2.weight")[32], 32)
     vec("V_V21", g("vis_fc2.2.weight")[0], 32)
     vec("V_R2", g("rgb_fc.4.weight")[0], 8)
@@ -734,8 +734,8 @@ def emulate_color_mfma(blob, geo, rf64, rd, m, G, x3_blob=None):
     def layer(aname, bname, bsrc):
         off, nb, ns = CM_LAYOUT[aname]
         boff = CM_LAYOUT[bname][0]
-        Bv = blob[boff:boff + nb * 32].reshape(nb, 16, 2).astype(np.float64)
-        acc = [np.stack([Bv[b, r, h] for r in range(16)], 1) for b in range(nb)]
+        Bv = blob[boff:boff + nb * 32].reshape(nb, 2, 16).astype(np.float64)
+        acc = [np.stack([Bv[b, h, r] for r in range(16)], 1) for b in range(nb)]
         if x3_blob is None:
             A = blob[off:off + nb * ns * 64].reshape(nb, ns, 64).astype(np.float64)
             for s in range(ns):
@@ -793,8 +793,8 @@ def emulate_color_mfma(blob, geo, rf64, rd, m, G, x3_blob=None):
 
     def dot_all(name, regs, nreg, bias_v):                    # per-lane partial dot over its registers + the other half's
         off = CM_LAYOUT[name][0]
-        wv = blob[off:off + 32].reshape(16, 2).astype(np.float64)
-        part = sum(regs[:, r] * wv[r, h] for r in range(nreg))
+        wv = blob[off:off + 32].reshape(2, 16).astype(np.float64)
+        part = sum(regs[:, r] * wv[h, r] for r in range(nreg))
         return part + part[lane ^ 32] + bias_v
     vis = sig(elu(dot_all("V_V1X", t32, 16, float(blob[so + 1])))) * ml
     x32 = x32 + elu(v1[0])
