@@ -409,9 +409,11 @@ def cat_z(rays_o, rays_d, z, new_z, sdf_v, volume, maskvol, W):
 # a20: Projector.compute / compute_view_independent (projector.py:15-62,96-228,231-425,
 #      render_utils.py:54-120, ops/back_project.py:89-129)
 # ----------------------------------------------------------------------------------------------
-def project_pts(pts, K, w2c, W_img, H_img):
-    """cam2pixel with padding 'zeros': Z.clamp(min=1e-3), out-of-range coordinate -> 2.  pts [P,3] -> gx,gy [V,P]."""
-    Pm = K @ w2c[:, :3, :]
+def project_pts(pts, K, w2c, W_img, H_img, Pm=None):
+    """cam2pixel with padding 'zeros': Z.clamp(min=1e-3), out-of-range coordinate -> 2.  pts [P,3] -> gx,gy [V,P].
+    Pm [V,3,4]: the product K @ w2c[:, :3] if the caller already has it (the C ABI's `proj`)."""
+    if Pm is None:
+        Pm = K @ w2c[:, :3, :]
     p = torch.einsum("vij,pj->vpi", Pm[:, :, :3], pts) + Pm[:, None, :, 3]
     Z = p[..., 2].clamp(min=1e-3)
     gx = 2 * (p[..., 0] / Z) / (W_img - 1) - 1
@@ -431,16 +433,18 @@ def ray_diff(pts, query_dir, cam_pos):
     return torch.cat([d / n.clamp(min=1e-6), dot], -1)
 
 
-def projector(pts, volume, maskvol, feat_maps, color_maps, w2cs, K, img_wh, query_cam=None, normals=None):
-    """pts [P,3] -> geo [P,16], rgb_feat [V,P,59] (colour first), ray_diff [V,P,4], mask [V,P]."""
+def projector(pts, volume, maskvol, feat_maps, color_maps, w2cs, K, img_wh, query_cam=None, normals=None, proj=None, cam_pos=None):
+    """pts [P,3] -> geo [P,16], rgb_feat [V,P,59] (colour first), ray_diff [V,P,4], mask [V,P].
+    proj [V,3,4] / cam_pos [V,3] may be given instead of (K, w2cs) (the form the C ABI takes)."""
     geo = trilinear_zeros(volume, pts)
     inside = (pts.abs() < 1).all(1)
     gmask = inside & (trilinear_zeros(maskvol[None], pts)[:, 0] > 0)
-    gx, gy = project_pts(pts, K, w2cs, img_wh[0], img_wh[1])
+    gx, gy = project_pts(pts, K, w2cs, img_wh[0], img_wh[1], Pm=proj)
     pmask = (gx.abs() < 1) & (gy.abs() < 1)
     feats = bilinear_zeros(feat_maps, gx.T, gy.T).permute(1, 0, 2)      # [V,P,56]
     cols = bilinear_zeros(color_maps, gx.T, gy.T).permute(1, 0, 2)
-    cam_pos = torch.inverse(w2cs)[:, :3, 3]
+    if cam_pos is None:
+        cam_pos = torch.inverse(w2cs)[:, :3, 3]
     if normals is None:
         q = query_cam[None] - pts
         q = q / (q.norm(dim=-1, keepdim=True) + 1e-6)
@@ -489,7 +493,8 @@ def rendering_network(RW, geo, rgb_feat, rdiff, mask):
 # a16, a21: render / render_core (sparse_neus_renderer.py:171-635), general rendering; perturb > 0 when t_rand is given
 # ----------------------------------------------------------------------------------------------
 def render(rays_o, rays_d, near, far, volume, maskvol, W, RW, variance, feat_maps, color_maps, w2cs, K, img_wh,
-           query_c2w, n_samples=64, n_importance=64, alpha_inter_ratio=1.0, background_rgb=1.0, t_rand=None, diag=None, trace=None):
+           query_c2w, n_samples=64, n_importance=64, alpha_inter_ratio=1.0, background_rgb=1.0, t_rand=None, diag=None, trace=None,
+           proj=None, cam_pos=None):
     """t_rand [R, n_samples]: the stratified jitter of :506-515 (the reference draws torch.rand(z_vals.shape) on the host).
     diag: see sample_pdf_det.  trace (list or None): receives per up-sampling round the sampler's input state and output
     dict(z [R,S], sdf [R,S], inv_s, new_z [R,n]) -- lets a test drive the HIP sampler stage with IDENTICAL inputs."""
@@ -509,11 +514,11 @@ def render(rays_o, rays_d, near, far, volume, maskvol, W, RW, variance, feat_map
             trace.append(dict(z=z.clone(), sdf=s.clone(), inv_s=64.0 * 2 ** i, new_z=nz.clone()))
         z, s = cat_z(rays_o, rays_d, z, nz, s, volume, maskvol, W)
     return render_core(rays_o, rays_d, z, sample_dist, volume, maskvol, W, RW, variance, feat_maps, color_maps, w2cs, K, img_wh,
-                       query_c2w, alpha_inter_ratio, background_rgb)
+                       query_c2w, alpha_inter_ratio, background_rgb, proj=proj, cam_pos=cam_pos)
 
 
 def render_core(rays_o, rays_d, z, sample_dist, volume, maskvol, W, RW, variance, feat_maps, color_maps, w2cs, K, img_wh, query_c2w,
-                alpha_inter_ratio=1.0, background_rgb=1.0):
+                alpha_inter_ratio=1.0, background_rgb=1.0, proj=None, cam_pos=None):
     """Everything of render() after the hierarchical sampling (sparse_neus_renderer.py:555-635 + render_core :171-455) for GIVEN
     sorted sample depths z [R,S]."""
     R = rays_o.shape[0]
@@ -531,7 +536,7 @@ def render_core(rays_o, rays_d, z, sample_dist, volume, maskvol, W, RW, variance
     sdf_v[mb] = sdf(pts[mb], volume, W)[0][:, 0]
     grad[mb] = sdf_grad(pts[mb], volume, W)
     geo, rf, rdiff, vmask = projector(pts, volume, maskvol, feat_maps, color_maps, w2cs, K, img_wh,
-                                      query_cam=query_c2w[:3, 3])
+                                      query_cam=query_c2w[:3, 3], proj=proj, cam_pos=cam_pos)
     rgb, nvalid = rendering_network(RW, geo, rf, rdiff, vmask)
     inv_s = torch.exp(variance * 10.0).clip(1e-6, 1e6)
     tdot = (dirs * grad).sum(-1)

@@ -1,0 +1,227 @@
+"""CPU stand-ins for ``one-2-3-45_amd.ops`` backed by the oracle -- TEST INFRASTRUCTURE ONLY.
+
+Purpose: run the reference's UNCHANGED ``GenericTrainer`` (models/trainer_generic.py) through ``dropin.install()`` in the build
+container, where ``/root/reference`` exists but no GPU does, so that the trainer's own control flow (dict plumbing, ``.to()``,
+chunking, ``validate_colored_mesh``'s host round trips, file outputs) is exercised against the mirror modules and shims.  Every
+stand-in takes exactly the arguments of the ops function it replaces and returns tensors of the same shape / dtype / layout; the
+arithmetic is the oracle's (oracle/recon.py, oracle/mc.c).  Nothing here is imported by the product."""
+import importlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import mc as omc
+from oracle import recon as O
+
+pkg = importlib.import_module("one-2-3-45_amd")
+_SDF, _COL, _KEEP = {}, {}, []
+
+
+def _t(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float32)
+
+
+def _origin(o):
+    return torch.as_tensor(np.asarray(o.detach().cpu() if torch.is_tensor(o) else o, np.float32)).reshape(-1)[:3]
+
+
+# ------------------------------------------------------------------------------------------------ cost volume
+def costvol_index(proj, V, H, W, dims, voxel_size, origin, min_views=1):
+    lat = O.voxel_lattice([int(d) for d in dims])
+    _, _, _, m = O.project(lat * voxel_size + _origin(origin)[None], proj, H, W)
+    cnt = m.sum(1)
+    idx = torch.nonzero(cnt > min_views)[:, 0]
+    coords = torch.cat([lat[idx].to(torch.int32), torch.zeros(len(idx), 1, dtype=torch.int32)], 1)
+    row = torch.full((lat.shape[0],), -1, dtype=torch.int32)
+    row[idx] = torch.arange(len(idx), dtype=torch.int32)
+    return cnt.to(torch.uint8), row, coords, int(len(idx))
+
+
+def _rows(feats_nhwc, proj, voxel_size, origin, coords):
+    feats = feats_nhwc.permute(0, 3, 1, 2)
+    H, W = feats.shape[2:]
+    gx, gy, _, m = O.project(coords[:, :3].float() * voxel_size + _origin(origin)[None], proj, H, W)
+    f = O.bilinear_zeros(feats, gx, gy)
+    c = (1.0 / (m.sum(1).float() + 1e-5))[:, None]
+    s1, s2 = f.sum(1), (f * f).sum(1)
+    return torch.cat([s2 * c - (s1 * c) ** 2, s1 * c], 1)
+
+
+def costvol_gather(feats_nhwc, proj, dims, voxel_size, origin, cnt, coords):
+    return _rows(feats_nhwc, proj, voxel_size, origin, coords)
+
+
+def visible_count_list(proj, H, W, voxel_size, origin, coords):
+    _, _, _, m = O.project(coords[:, :3].float() * voxel_size + _origin(origin)[None], proj, H, W)
+    return m.sum(1).to(torch.uint8)
+
+
+def costvol_gather_list(feats_nhwc, proj, voxel_size, origin, cnt_row, coords):
+    return _rows(feats_nhwc, proj, voxel_size, origin, coords)
+
+
+def build_index_grid(coords, ts, cells):
+    nx, ny, nz = (int(c) for c in cells)
+    g = torch.full((nx * ny * nz,), -1, dtype=torch.int32)
+    c = coords.long() // ts
+    g[(c[:, 0] * ny + c[:, 1]) * nz + c[:, 2]] = torch.arange(coords.shape[0], dtype=torch.int32)
+    return g
+
+
+def scatter_dense(rows, row_of_voxel, dims, want_cf=True):
+    dx, dy, dz = (int(d) for d in dims)
+    C = rows.shape[1]
+    cl = torch.zeros(dx * dy * dz, C)
+    v = row_of_voxel >= 0
+    cl[v] = rows[row_of_voxel[v].long()]
+    cl = cl.view(dx, dy, dz, C)
+    cf = cl.permute(3, 0, 1, 2).contiguous()[None] if want_cf else None
+    return cl, cf, v.float().view(1, 1, dx, dy, dz)
+
+
+def costreg_forward(self, feat, coords, grid0, dims):
+    """CostRegNet.forward: the same rows in the same order from the oracle's sparse U-Net."""
+    w = {n: (K.cpu(), g.cpu(), b.cpu()) for n, (K, g, b) in self.p.items()}
+    out, extra = O.sparse_costreg(feat, coords, w)
+    self.level_sizes = tuple(len(lv.xyz) for lv in extra["levels"])
+    return out
+
+
+def abn_forward(self, x, want_nhwc=False):
+    """featurenet.InPlaceABN.forward."""
+    y = O.abn_train(x, self.weight.detach(), self.bias.detach(), self.eps, self.slope, self.abs_gamma)
+    return (y, y.permute(0, 2, 3, 1).contiguous()) if want_nhwc else y
+
+
+# ------------------------------------------------------------------------------------------------ networks
+def sdf_mlp(blob, vol_cl, pts=None, variant=0, grid_R=0, sign=1.0, index=None, n_dev=None, want_lat=False, out=None, lat_in=None,
+            precision=None):
+    W = _SDF[blob.data_ptr()]
+    volume = vol_cl.permute(3, 0, 1, 2)
+    if pts is None:
+        lin = torch.linspace(-1, 1, int(grid_R))
+        pts = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(-1, 3)
+    P = pts.shape[0]
+    res = out or {}
+    res.setdefault("sdf", torch.zeros(P))
+    if variant == 1:
+        res.setdefault("feat", torch.zeros(P, 128))
+    if variant == 2:
+        res.setdefault("grad", torch.zeros(P, 3))
+    if want_lat:
+        res.setdefault("lat", torch.zeros(P, 16))
+    sel = torch.arange(P) if index is None else index.long()
+    if sel.numel() == 0:
+        return res
+    p = pts[sel]
+    if lat_in is not None:
+        lat = lat_in[sel]
+        y = O.sdf_mlp(p, lat, W)
+    else:
+        y, lat = O.sdf(p, volume, W)
+    res["sdf"][sel] = sign * y[:, 0]
+    if variant == 1:
+        res["feat"][sel] = y
+    if variant == 2:
+        res["grad"][sel] = O.sdf_grad(p, volume, W)
+    if want_lat:
+        res["lat"][sel] = lat
+    return res
+
+
+def pack_color_maps(feat_nchw, color_nchw):
+    V, _, H, W = feat_nchw.shape
+    return torch.cat([color_nchw, feat_nchw, torch.zeros(V, 5, H, W)], 1).permute(0, 2, 3, 1).contiguous()
+
+
+def _maps(cmaps):
+    return cmaps[..., 3:59].permute(0, 3, 1, 2).contiguous(), cmaps[..., :3].permute(0, 3, 1, 2).contiguous()
+
+
+def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=None, normals=None, index=None, n_dev=None,
+                 want_nviews=True, mfma=False):
+    RW = _COL[blob.data_ptr()]
+    D = vol_cl.shape[0]
+    fm, cm = _maps(cmaps)
+    P = pts.shape[0]
+    rgb = torch.zeros(P, 3)
+    nv = torch.zeros(P, dtype=torch.uint8) if want_nviews else None
+    sel = torch.arange(P) if index is None else index.long()
+    if sel.numel():
+        nrm = None if normals is None else F.normalize(normals[sel], p=2, dim=-1, eps=1e-6)
+        geo, rf, rd, vm = O.projector(pts[sel], vol_cl.permute(3, 0, 1, 2), maskvol.view(D, D, D), fm, cm, None, None, (cmaps.shape[2], cmaps.shape[1]),
+                                      query_cam=query_cam, normals=nrm, proj=proj, cam_pos=cam_pos)
+        c, n = O.rendering_network(RW, geo, rf, rd, vm)
+        rgb[sel] = c
+        if want_nviews:
+            nv[sel] = n.to(torch.uint8)
+    return rgb, nv
+
+
+def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64, inv_s=None, alpha_inter_ratio=1.0, background=1.0,
+                query_cam=None, want_z=False, t_rand=None):
+    W, RW = _SDF[scene["sdf_blob"].data_ptr()], _COL[scene["color_blob"].data_ptr()]
+    D = scene["vol_cl"].shape[0]
+    fm, cm = _maps(scene["cmaps"])
+    q = torch.eye(4)
+    q[:3, 3] = query_cam
+    r = O.render(rays_o, rays_d, torch.tensor(float(near)), torch.tensor(float(far)), scene["vol_cl"].permute(3, 0, 1, 2), scene["maskvol"].view(D, D, D),
+                 W, RW, torch.tensor(float(np.log(inv_s) / 10.0)), fm, cm, None, None, (scene["cmaps"].shape[2], scene["cmaps"].shape[1]), q,
+                 n_samples, n_importance, alpha_inter_ratio, background, t_rand=t_rand, proj=scene["proj"], cam_pos=scene["cam_pos"])
+    R, S = rays_o.shape[0], n_samples + n_importance
+    pm = r["inside_sphere"]
+    ge = torch.zeros(R, 2)
+    ge[0, 1] = pm.sum()
+    ge[0, 0] = r["gradient_error_fine"] * (pm.sum() + 1e-5)
+    o = dict(mid_z=r["mid_z_vals"].t().contiguous(), pm=pm.t().contiguous(), sdf=r["sdf"].view(R, S).t().contiguous(),
+             grad=r["gradients"].permute(1, 0, 2).contiguous(), color=r["color_fine"], depth=r["depth"][:, 0], weights=r["weights"].t().contiguous(),
+             cdf=r["cdf_fine"].t().contiguous(), weights_sum=r["weights_sum"][:, 0], weights_max=r["weights_max"][:, 0],
+             depth_var=r["depth_variance"][:, 0], alpha_sum=torch.full((R,), float(r["alpha_sum"])), grad_err=ge,
+             color_mask=r["color_fine_mask"][:, 0].to(torch.uint8))
+    if want_z:
+        o["z_vals"] = r["z_vals"].t().contiguous()
+    return o
+
+
+def marching_cubes(u, iso=0.0, index_dtype=torch.int64):
+    v, t = omc.marching_cubes(u.detach().cpu().numpy(), float(iso))
+    return torch.from_numpy(v), torch.from_numpy(t).to(index_dtype)
+
+
+def prune_dilate(sdf_vol, mask_vol, D, threshold, radius=3):
+    occ = (sdf_vol.view(D, D, D).abs() < threshold).float()[None, None]
+    occ = F.max_pool3d(occ, 2 * radius + 1, stride=1, padding=radius)[0, 0] > 0
+    return (occ & (mask_vol.view(D, D, D) > 0)).reshape(-1).to(torch.uint8)
+
+
+# ------------------------------------------------------------------------------------------------ installation
+def install(monkeypatch):
+    """Patch the ops layer (and the three places that reach the HIP library without going through it) for one test."""
+    ops = importlib.import_module("one-2-3-45_amd.ops")
+    weights = importlib.import_module("one-2-3-45_amd.weights")
+    costreg = importlib.import_module("one-2-3-45_amd.costreg")
+    featurenet = importlib.import_module("one-2-3-45_amd.featurenet")
+    for name in ("costvol_index", "costvol_gather", "visible_count_list", "costvol_gather_list", "build_index_grid", "scatter_dense", "sdf_mlp",
+                 "pack_color_maps", "color_points", "render_rays", "marching_cubes", "prune_dilate"):
+        monkeypatch.setattr(ops, name, globals()[name])
+    monkeypatch.setattr(costreg.CostRegNet, "forward", costreg_forward)
+    monkeypatch.setattr(featurenet.InPlaceABN, "forward", abn_forward)
+    # the mirrors hand packed blobs to ops: remember which parameters each blob was packed from
+    pack_sdf = weights.pack_sdf_blob
+
+    def pack_sdf_reg(W):
+        arr = pack_sdf(W)
+        _KEEP.append(arr)
+        _SDF[arr.ctypes.data] = {k: _t(v) for k, v in W.items()}
+        return arr
+    monkeypatch.setattr(weights, "pack_sdf_blob", pack_sdf_reg)
+    for fn in ("pack_color_blob", "pack_color_mfma_blob", "pack_color_x3_blob"):
+        orig = getattr(weights, fn)
+
+        def reg(sd, _orig=orig):
+            arr = _orig(sd)
+            _KEEP.append(arr)
+            _COL[arr.ctypes.data] = {k: _t(v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in sd.items()}
+            return arr
+        monkeypatch.setattr(weights, fn, reg)
