@@ -151,9 +151,7 @@ def kernel_times(wt, vol, inp, outs, D, reps=5, sdf_precision=None, color_precis
     res["sdf_grad_ms"] = timed(lambda: ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=2, index=idx, out=o2, precision=sdf_precision))
     res["sdf_mlp_ms"] = timed(lambda: ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=0, out={"sdf": o2["sdf"]}, precision=sdf_precision))
     V = inp["imgs"].shape[0]
-    if V > 32:
-        blob, mode = wt.color_blob, False
-    elif color_precision == "f16x3":
+    if color_precision == "f16x3":
         blob, mode = wt.color_xblob, "x3"
     else:
         blob, mode = wt.color_mblob, True

@@ -151,10 +151,10 @@ typedef struct O2345RenderIO {
     float* mid_z; float* dists; float* pm; float* sdf; float* grad; float* rgb; uint8_t* nviews;
     float* color; float* depth; float* weights; float* cdf; float* weights_sum; float* weights_max; float* depth_var;
     float* alpha_sum; float* grad_err; uint8_t* color_mask; float* z_vals;
-    const float* color_mfma_blob;   /* optional: use the MFMA colour kernel (V <= 32) */
+    const float* color_mfma_blob;   /* optional: use the fp32 matrix-core colour kernels */
     int sdf_bf16;                   /* SDF network mode: 0 exact fp32 MFMA; 1 bf16 throughput mode; 2 split-f16 ("f16x3", fp32-class
                                      * accuracy: o2345_sdf_mlp_x3 / o2345_sdf_grad_x3) */
-    const float* color_x3_blob;     /* optional: split-f16 colour kernel (takes precedence over color_mfma_blob; V <= 32) */
+    const float* color_x3_blob;     /* optional: split-f16 colour kernels (take precedence over color_mfma_blob) */
     const float* t_rand;            /* optional [R][n_samples]: the reference's perturb > 0 jitter, drawn by the caller (ABI 1.2) */
 } O2345RenderIO;
 size_t o2345_render_workspace_bytes(int R, int n_samples, int n_importance);
@@ -172,7 +172,8 @@ int o2345_color_points(const float* blob, const float* vol_cl, const float* mask
                        const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
                        const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
                        const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
-/* same function with every linear layer on fp32 MFMA (V <= 32); blob from weights.pack_color_mfma_blob */
+/* same function with every linear layer on fp32 MFMA (any V >= 1: k_color_mfma for power-of-two view counts up to 32, k_color_pts
+ * otherwise -- csrc/color_mfma.hip, csrc/color_pts.hip); blob from weights.pack_color_mfma_blob */
 int o2345_color_mfma_blob_floats(void);
 int o2345_color_points_mfma(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
                             const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,

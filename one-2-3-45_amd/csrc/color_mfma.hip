@@ -20,199 +20,9 @@
 //               in fp32 as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (75 MFMAs of 32 cycles per tile).  The per-half
 //               k enumeration is the same (register r of the fp32 form = slot 8s+t of step s), so the x3 blob is a regrouping
 //               of the fp32 one (weights.pack_color_x3_blob).
-#include "common.h"
-#include "geom_math.h"
+#include "color_net.h"
 
 namespace o2345 {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
-#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-
-// ---- blob layout (floats) -- must match weights.CM_SEGS / CM_BIAS -------------------------------------------------
-constexpr int CM_A_RD0 = 0;                         // [1][2][64]
-constexpr int CM_A_RD1 = CM_A_RD0 + 1 * 2 * 64;     // [2][8][64]
-constexpr int CM_A_B0 = CM_A_RD1 + 2 * 8 * 64;      // [2][32][64]
-constexpr int CM_A_B1 = CM_A_B0 + 2 * 32 * 64;      // [1][32][64]
-constexpr int CM_A_V0 = CM_A_B1 + 32 * 64;          // [1][16][64]
-constexpr int CM_A_V1 = CM_A_V0 + 16 * 64;          // [1][16][64]  (rows 0..31 of vis_fc.2; row 32 is a dot product)
-constexpr int CM_A_V20 = CM_A_V1 + 16 * 64;         // [1][16][64]
-constexpr int CM_A_R0 = CM_A_V20 + 16 * 64;         // [1][19][64]
-constexpr int CM_A_R1 = CM_A_R0 + 19 * 64;          // [1][8][64]
-constexpr int CM_BIAS0 = CM_A_R1 + 8 * 64;          // biases / per-lane vectors, [block][half][16] each
-constexpr int CM_B_RD0 = CM_BIAS0, CM_B_RD1 = CM_B_RD0 + 32, CM_B_B0 = CM_B_RD1 + 64, CM_B_B1 = CM_B_B0 + 64,
-              CM_B_V0 = CM_B_B1 + 32, CM_B_V1 = CM_B_V0 + 32, CM_B_V20 = CM_B_V1 + 32, CM_B_R0 = CM_B_V20 + 32,
-              CM_B_R1 = CM_B_R0 + 32, CM_V_V1X = CM_B_R1 + 32, CM_V_V21 = CM_V_V1X + 32, CM_V_R2 = CM_V_V21 + 32;
-constexpr int CM_W_S = CM_V_R2 + 32;                // [144][64]
-constexpr int CM_S = CM_W_S + 144 * 64;             // [s, bias vis_fc.2[32], bias vis_fc2.2, bias rgb_fc.4]
-constexpr int CM_TOTAL = CM_S + 4;
-// split-f16 blob: A segments [block][k-step of 16][hi|lo][64 lanes][8 f16 = 4 floats], then the fp32 tail (CM_BIAS0 .. CM_TOTAL)
-constexpr int CX_A_RD0 = 0;                         // [1][1]
-constexpr int CX_A_RD1 = CX_A_RD0 + 1 * 1 * 512;    // [2][1]
-constexpr int CX_A_B0 = CX_A_RD1 + 2 * 1 * 512;     // [2][4]
-constexpr int CX_A_B1 = CX_A_B0 + 2 * 4 * 512;      // [1][4]
-constexpr int CX_A_V0 = CX_A_B1 + 4 * 512;          // [1][2]
-constexpr int CX_A_V1 = CX_A_V0 + 2 * 512;          // [1][2]
-constexpr int CX_A_V20 = CX_A_V1 + 2 * 512;         // [1][2]
-constexpr int CX_A_R0 = CX_A_V20 + 2 * 512;         // [1][3]
-constexpr int CX_A_R1 = CX_A_R0 + 3 * 512;          // [1][1]
-constexpr int CX_A_END = CX_A_R1 + 1 * 512;
-constexpr int CX_TOTAL = CX_A_END + (CM_TOTAL - CM_BIAS0);
-
-struct ColorMArgs {
-    const float* blob;
-    const float* vol_cl; const float* maskvol; int D;
-    const float* cmaps; const float* proj; const float* cam_pos; int V, H, W_img;
-    const float* pts; const int* index; const int* n_dev; long long n;
-    const float* query_cam; const float* normals;
-    float* out_rgb; uint8_t* out_nviews;
-};
-
-// ELU is evaluated ~150 times per lane and tile (a quarter of the kernel's VALU instructions), so the whole network runs in a
-// log2(e)-scaled domain: every layer that feeds an ELU produces y = log2(e) * x (its weights / bias are pre-scaled on the host,
-// weights.pack_color_mfma_blob) and the activation is   ELU_y(y) = log2(e) * ELU(x) = max(y, log2(e) * (min(2^y, 1) - 1)):
-// v_exp_f32 with its [0,1] output clamp, one fma, one max -- no multiply by log2(e) in front of the exponential.  The scale
-// cancels in the next layer (ln2 * log2e = 1, so hidden-layer weights are unchanged; only biases and the first / last layers
-// carry a factor).  e^x - 1 has an ABSOLUTE error of ~1e-7 (one ulp of 1.0), which is what matters downstream.
-// Reciprocals are the hardware v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence.
-constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
-__device__ __forceinline__ float celu(float y) {
-    const float t = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(y), 0.f, 1.f);
-    return fmaxf(y, fmaf(t, LOG2E, -LOG2E));
-}
-// two at a time: the multiply-add is one packed-fp32 instruction for both (consecutive accumulator registers are an aligned pair)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 celu2(float y0, float y1) {
-    f32x2 t;
-    t[0] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(y0), 0.f, 1.f);
-    t[1] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(y1), 0.f, 1.f);
-    const f32x2 e = __builtin_elementwise_fma(t, f32x2{LOG2E, LOG2E}, f32x2{-LOG2E, -LOG2E});
-    return f32x2{fmaxf(y0, e[0]), fmaxf(y1, e[1])};
-}
-__device__ __forceinline__ float crcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float csigm(float z) { return crcp(1.f + __builtin_amdgcn_exp2f(-z)); }      // sigmoid of z / log2(e)
-
-// NB output blocks, N k-steps whose B operands are b[0..N-1]; A operands come from LDS, next step prefetched
-template <int NB, int NST, int N>
-__device__ __forceinline__ void cm_run(f32x16 (&acc)[NB], const float* A /* + lane */, int step0, const float (&b)[N]) {
-    float cur[NB], nxt[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) cur[nb] = A[(nb * NST + step0) * 64];
-#pragma unroll
-    for (int r = 0; r < N; ++r) {
-        if (r + 1 < N) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) nxt[nb] = A[(nb * NST + step0 + r + 1) * 64];
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA32(cur[nb], b[r], acc[nb]);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) cur[nb] = nxt[nb];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// split-f16 form of the same step loop: b[] is the per-half operand list of the fp32 form, consumed 8 per MFMA step
-struct Split8 { h16x8 hi, lo; };
-typedef _Float16 hh16x2 __attribute__((ext_vector_type(2)));
-// hi = f16(x) rounded toward zero, lo = f16(x - hi) with the exact difference from one v_fma_mix_f32 (see csrc/sdf_mlp_x3.hip)
-__device__ __forceinline__ float opaque_minus_one() {
-    float m1 = -1.f;
-    asm volatile("" : "+v"(m1));
-    return m1;
-}
-template <int N>
-__device__ __forceinline__ Split8 split8(const float (&b)[N], int s0, float m1) {      // s0 compile-time after unrolling
-    union { h16x8 v8; h16x2 v2[4]; hh16x2 w2[4]; } hi, lo;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float x = (s0 + 2 * i < N) ? b[s0 + 2 * i < N ? s0 + 2 * i : 0] : 0.f;
-        const float y = (s0 + 2 * i + 1 < N) ? b[s0 + 2 * i + 1 < N ? s0 + 2 * i + 1 : 0] : 0.f;
-        hi.v2[i] = __builtin_amdgcn_cvt_pkrtz(x, y);
-        lo.v2[i] = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)hi.w2[i][0], m1, x), __builtin_fmaf((float)hi.w2[i][1], m1, y));
-    }
-    return {hi.v8, lo.v8};
-}
-template <int NB, int N>
-__device__ __forceinline__ void cx_run(f32x16 (&acc)[NB], const float4* A /* segment + lane */, const float (&b)[N], float m1) {
-    constexpr int NS = (N + 7) / 8;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const Split8 sp = split8(b, 8 * s, m1);
-        h16x8 ahi[NB], alo[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            ahi[nb] = __builtin_bit_cast(h16x8, A[((nb * NS + s) * 2 + 0) * 64]);
-            alo[nb] = __builtin_bit_cast(h16x8, A[((nb * NS + s) * 2 + 1) * 64]);
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA_F16(alo[nb], sp.hi, acc[nb]);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA_F16(ahi[nb], sp.lo, acc[nb]);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA_F16(ahi[nb], sp.hi, acc[nb]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-// one layer's matrix part in either form
-template <bool X3, int NB, int N>
-__device__ __forceinline__ void cm_layer(f32x16 (&acc)[NB], const float* lds, int lane, int off32, int offx, const float (&b)[N], float m1) {
-    if constexpr (X3) cx_run<NB, N>(acc, reinterpret_cast<const float4*>(lds + offx) + lane, b, m1);
-    else cm_run<NB, N, N>(acc, lds + lane + off32, 0, b);
-}
-
-// biases are stored [block][half][16 registers]: four 16-byte LDS reads straight into the accumulator tuple
-template <int NB>
-__device__ __forceinline__ void cm_bias(f32x16 (&acc)[NB], const float* bias, int h) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const float4* p = reinterpret_cast<const float4*>(bias + (nb * 2 + h) * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 t = p[q];
-            acc[nb][4 * q] = t.x; acc[nb][4 * q + 1] = t.y; acc[nb][4 * q + 2] = t.z; acc[nb][4 * q + 3] = t.w;
-        }
-    }
-}
-
-// Reductions over the G view lanes of a point (G consecutive lanes, G | 32) with DPP lane permutes instead of
-// ds_bpermute: xor 1 / xor 2 are quad_perm, then row_half_mirror (i <-> 7-i) and row_mirror (i <-> 15-i) combine quads
-// that already hold their own partial result; only the 16 <-> 16 step of G = 32 goes through the LDS crossbar.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-#define O2345_GROUP_REDUCE(NAME, OP)                                                   \
-    template <int G>                                                                   \
-    __device__ __forceinline__ float NAME(float v) {                                   \
-        v = OP(v, dpp_mov<0xB1>(v));                        /* quad_perm [1,0,3,2] */  \
-        v = OP(v, dpp_mov<0x4E>(v));                        /* quad_perm [2,3,0,1] */  \
-        if (G >= 8) v = OP(v, dpp_mov<0x141>(v));           /* row_half_mirror     */  \
-        if (G >= 16) v = OP(v, dpp_mov<0x140>(v));          /* row_mirror          */  \
-        if (G >= 32) v = OP(v, __shfl_xor(v, 16));                                     \
-        return v;                                                                      \
-    }
-__device__ __forceinline__ float op_add(float a, float b) { return a + b; }
-O2345_GROUP_REDUCE(gsum, op_add)
-O2345_GROUP_REDUCE(gmin, fminf)
-O2345_GROUP_REDUCE(gmax, fmaxf)
-#undef O2345_GROUP_REDUCE
-
-__device__ __forceinline__ void cm_project(const float* __restrict__ P, float x, float y, float z, int H, int W, float& gx, float& gy) {
-    const float X = P[0] * x + P[1] * y + P[2] * z + P[3];
-    const float Y = P[4] * x + P[5] * y + P[6] * z + P[7];
-    const float Z = fmaxf(P[8] * x + P[9] * y + P[10] * z + P[11], 1e-3f);
-    // a / b as a * rcp(b) with one Newton step on the quotient (q += (a - b q) * r): within 1 ulp of the IEEE quotient (almost
-    // always identical) in 3 instructions instead of the ~12 of the division sequence; the reciprocals are shared
-    const float rz = crcp(Z), rw = crcp((float)(W - 1)), rh = crcp((float)(H - 1));
-    auto div = [](float a_, float b_, float r_) { const float q = a_ * r_; return fmaf(fmaf(-b_, q, a_), r_, q); };
-    gx = div(2.f * div(X, Z, rz), (float)(W - 1), rw) - 1.f;
-    gy = div(2.f * div(Y, Z, rz), (float)(H - 1), rh) - 1.f;
-    if (gx > 1.f || gx < -1.f) gx = 2.f;
-    if (gy > 1.f || gy < -1.f) gy = 2.f;
-}
 
 template <int G, bool X3>
 __global__ __launch_bounds__(768) void k_color_mfma(ColorMArgs a) {
@@ -479,8 +289,8 @@ using namespace o2345;
 
 extern "C" {
 
-int o2345_color_mfma_blob_floats(void) { return CM_TOTAL; }
-int o2345_color_x3_blob_floats(void) { return CX_TOTAL; }
+int o2345_color_mfma_blob_floats(void) { return CM_TOTAL2; }
+int o2345_color_x3_blob_floats(void) { return CX_TOTAL2; }
 
 static int color_mfma_launch(bool x3, const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
                              const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
@@ -488,8 +298,23 @@ static int color_mfma_launch(bool x3, const float* blob, const float* vol_cl, co
                              const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream) {
     O2345_REQUIRE(blob && vol_cl && maskvol && cmaps && proj && cam_pos && pts && out_rgb, "color_points_mfma: null pointer");
     O2345_REQUIRE((query_cam != nullptr) != (normals != nullptr), "color_points_mfma: give exactly one of query_cam / normals");
-    O2345_REQUIRE(V >= 1 && V <= 32, "color_points_mfma: V must be in [1,32] (got %d)", V);
+    O2345_REQUIRE(V >= 1, "color_points_mfma: V must be >= 1 (got %d)", V);
     if (n <= 0 && !n_dev) return 0;
+    {
+        // Two kernels compute the same function: k_color_mfma (columns = (point, view) pairs, view count padded to a
+        // power of two <= 32) and k_color_pts (columns = points, any V).  On MI355X they are equally fast at V = 8 (45.5 vs 45.2 ms on 29.5 M
+        // points) and k_color_mfma wins at V = 32 (50 vs 55 ms); k_color_pts wins whenever the padding wastes lanes (V = 5..7, 9..15, 17..31)
+        // and is the only matrix-core form for V > 32.  O2345_COLOR_KERNEL=tiles|pts overrides the choice (A/B runs).
+        int G = 4;
+        while (G < V) G <<= 1;
+        bool use_pts = V > 32 || G != V;
+        const char* e = getenv("O2345_COLOR_KERNEL");
+        if (e && e[0] == 'p') use_pts = true;
+        if (e && e[0] == 't' && V <= 32) use_pts = false;
+        if (use_pts)
+            return color_pts_launch(x3 ? 1 : 0, blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals,
+                                    out_rgb, out_nviews, stream);
+    }
     ColorMArgs a{blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews};
     int G = 4;
     while (G < V) G <<= 1;

@@ -288,9 +288,9 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     hipLaunchKernelGGL(k_quirk_first100, dim3(1), dim3(128), 0, s, count, list, R, (int)S);
     if ((rc = sdf_eval(2, fpts, list, count, 0, io->sdf, io->grad))) return rc;
     if ((rc = o2345_view_count(fpts, (long long)S * R, io->maskvol, io->D, io->proj, io->V, io->H, io->W, io->nviews, stream))) return rc;
-    if (io->color_x3_blob && io->V <= 32)
+    if (io->color_x3_blob)
         rc = o2345_color_points_x3(io->color_x3_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, nullptr, stream);
-    else if (io->color_mfma_blob && io->V <= 32)
+    else if (io->color_mfma_blob)
         rc = o2345_color_points_mfma(io->color_mfma_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, nullptr, stream);
     else
         rc = o2345_color_points(io->color_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, nullptr, stream);

@@ -90,9 +90,9 @@ def render(wt, vol, proj, cam_pos, rays_o, rays_d, near, far, query_cam, n_sampl
     Note: the reference's per-512-ray-chunk quirks (cat_z_vals skipped when <= 1 new point of the CHUNK is valid; "first 100 points"
     when a chunk has no valid point) apply per CALL here -- identical when called per chunk, as the drop-in mirror does."""
     scene = dict(sdf_blob=wt.sdf_blob, color_blob=wt.color_blob, vol_cl=vol["vol_cl"], maskvol=vol["maskvol"],
-                 cmaps=vol["cmaps"], proj=proj, cam_pos=cam_pos, color_mfma_blob=wt.color_mblob if proj.shape[0] <= 32 else None,
+                 cmaps=vol["cmaps"], proj=proj, cam_pos=cam_pos, color_mfma_blob=wt.color_mblob,
                  sdf_precision=wt.sdf_precision, color_precision=wt.color_precision,
-                 color_x3_blob=wt.color_xblob if proj.shape[0] <= 32 else None)
+                 color_x3_blob=wt.color_xblob)
     return ops.render_rays(scene, rays_o, rays_d, near, far, n_samples, n_importance, wt.inv_s, 1.0, 1.0, query_cam, want_z, t_rand=t_rand)
 
 
@@ -110,7 +110,7 @@ def extract_mesh(wt, vol, proj, cam_pos, resolution, return_index_verts=False):
     if pts.shape[0] == 0:
         return verts, tris, torch.zeros(0, 3, device=pts.device), u
     g = ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=2, precision=prec)["grad"]
-    mf = proj.shape[0] <= 32
+    mf = True                                  # matrix-core kernels for every view count (k_color_pts beyond 32 views)
     if mf and wt.color_precision == "f16x3":
         rgb, _ = ops.color_points(wt.color_xblob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], proj, cam_pos, pts, normals=g,
                                   want_nviews=False, mfma="x3")

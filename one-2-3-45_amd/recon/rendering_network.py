@@ -66,7 +66,7 @@ class GeneralRenderingNetwork(nn.Module):
         (rgb [n_rays, n_samples, 3], valid_mask [n_rays]) like rendering_network.py:122-129."""
         if isinstance(geometry_feat, DeferredColour):
             d = geometry_feat
-            mf = d.proj.shape[0] <= 32
+            mf = True                          # matrix-core kernels for every view count (k_color_pts beyond 32 views)
             if mf and config.color_precision() == "f16x3":
                 blob, mode = self.x3_blob(), "x3"
             else:

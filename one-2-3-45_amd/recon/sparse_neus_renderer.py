@@ -116,8 +116,8 @@ class SparseNeuSRenderer(nn.Module):
         t_rand = torch.rand(R, self.n_samples).to(rays_o.device) if perturb > 0 else None
         scene = dict(sdf_blob=sdf_network.sdf_layer.blob(), color_blob=rendering_network.blob(), vol_cl=channel_last(conditional_volume),
                      maskvol=conditional_valid_mask_volume.reshape(-1).contiguous().float(), cmaps=cm, proj=proj, cam_pos=cam_pos,
-                     color_mfma_blob=rendering_network.mfma_blob() if proj.shape[0] <= 32 else None,
-                     color_x3_blob=rendering_network.x3_blob() if proj.shape[0] <= 32 else None)
+                     color_mfma_blob=rendering_network.mfma_blob(),
+                     color_x3_blob=rendering_network.x3_blob())
         inv_s = float(torch.exp(self.variance_network.variance.detach() * 10.0).clip(1e-6, 1e6))
         nt, ft = torch.as_tensor(near).reshape(-1).float(), torch.as_tensor(far).reshape(-1).float()
         if nt.numel() > 1 and (bool((nt != nt[0]).any()) or bool((ft != ft[0]).any())):

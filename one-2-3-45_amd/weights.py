@@ -577,6 +577,9 @@ def _cm_layout():
     off += 144 * 64
     segs["S_SCALAR"] = (off, 1, 1)          # [ |s| source, bias of vis_fc.2 row 32, bias of vis_fc2.2, bias of rgb_fc.4 ]
     off += 4
+    # the same view-independent rows as a matrix-core A operand for csrc/color_pts.hip (columns = points): 2 blocks x 72 per-half operands
+    segs["A_S"] = (off, 2, 72)
+    off += 2 * 72 * 64
     return segs, off
 
 
@@ -660,6 +663,13 @@ def pack_color_mfma_blob(sd):
     ws[:16] = w_b0[:, :16].T * L
     ws[16:16 + 59] = w_b0[:, 16:75].T
     ws[80:80 + 59] = w_b0[:, 75:134].T * N
+    # A_S: per-half operand s of the shared rows -> row of ws: geometry channel 8h+s (s < 8), mean of pixel float 32h+(s-8), variance of it
+    def shared_k(s_, h):
+        if s_ < 8:
+            return 8 * h + s_
+        f = 32 * h + (s_ - 8) % 32
+        return None if f >= 59 else (16 + f if s_ < 40 else 80 + f)
+    fill("A_S", np.ascontiguousarray(ws.T), plain, shared_k)
     so = CM_LAYOUT["S_SCALAR"][0]
     blob[so] = g("s").reshape(-1)[0]
     blob[so + 1], blob[so + 2], blob[so + 3] = g("vis_fc.2.bias")[32] * L, g("vis_fc2.2.bias")[0] * L, g("rgb_fc.4.bias")[0] * L
@@ -679,7 +689,8 @@ def _cx_layout():
 
 CX_LAYOUT, CX_A_END = _cx_layout()
 CM_TAIL0 = CM_LAYOUT["B_RD0"][0]                                   # first float of the fp32 tail (biases, shared rows, scalars)
-CX_BLOB_FLOATS = CX_A_END + CM_BLOB_FLOATS - CM_TAIL0
+CX_A_S = CX_A_END + (CM_LAYOUT["A_S"][0] - CM_TAIL0)             # x3 form of A_S: [2][9 k-steps][hi|lo][64][8 f16], behind the fp32 tail
+CX_BLOB_FLOATS = CX_A_S + 2 * 9 * 512
 
 
 def pack_color_x3_blob(sd):
@@ -698,7 +709,12 @@ def pack_color_x3_blob(sd):
         offx = CX_LAYOUT[name][0]
         sec = blob[offx:offx + nb * nsx * 512].view(np.float16).reshape(nb, nsx, 2, 64, 8)
         sec[:, :, 0], sec[:, :, 1] = hi, lo
-    blob[CX_A_END:] = b32[CM_TAIL0:]
+    blob[CX_A_END:CX_A_S] = b32[CM_TAIL0:CM_LAYOUT["A_S"][0]]
+    off = CM_LAYOUT["A_S"][0]
+    A = b32[off:off + 2 * 72 * 64].reshape(2, 9, 8, 64).transpose(0, 1, 3, 2)     # [b][k-step][lane][t]
+    hi, lo = f16_split(A)
+    sec = blob[CX_A_S:CX_A_S + 2 * 9 * 512].view(np.float16).reshape(2, 9, 2, 64, 8)
+    sec[:, :, 0], sec[:, :, 1] = hi, lo
     return blob
 
 

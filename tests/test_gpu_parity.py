@@ -274,10 +274,19 @@ def test_marching_cubes(dev, ops):
     assert v.shape[0] == 0 and t.shape[0] == 0
 
 
-@pytest.mark.parametrize("mfma,V", [(False, 4), (True, 4), (True, 8), (False, 8), (True, 12), (True, 32),
-                                    ("x3", 4), ("x3", 8), ("x3", 12), ("x3", 32)])
-def test_color_points(dev, ops, mfma, V):
-    """V = 4 / 8 / 12 / 32 exercise the G = 4 / 8 / 16 / 32 lane-group variants (incl. padded views for V = 12)."""
+@pytest.mark.parametrize("mfma,V,kernel", [(False, 4, None), (True, 4, "tiles"), (True, 8, "tiles"), (False, 8, None), (True, 12, "tiles"), (True, 32, "tiles"),
+                                           ("x3", 4, "tiles"), ("x3", 8, "tiles"), ("x3", 12, "tiles"), ("x3", 32, "tiles"),
+                                           (True, 4, "pts"), (True, 5, "pts"), (True, 8, "pts"), (True, 32, "pts"),
+                                           ("x3", 4, "pts"), ("x3", 5, "pts"), ("x3", 8, "pts"), ("x3", 12, "pts"), ("x3", 32, "pts"),
+                                           ("x3", 5, None), ("x3", 8, None)])
+def test_color_points(dev, ops, mfma, V, kernel, monkeypatch):
+    """Both matrix-core kernels in both numerical forms (+ the VALU kernel): "tiles" = k_color_mfma (columns = (point, view) pairs; V = 4 / 8 /
+    12 / 32 exercise its G = 4 / 8 / 16 / 32 lane groups incl. padded views for V = 12), "pts" = k_color_pts (columns = points, any V);
+    None = the library's own choice (k_color_pts when the view count is not a power of two)."""
+    if kernel is not None:
+        monkeypatch.setenv("O2345_COLOR_KERNEL", kernel)
+    else:
+        monkeypatch.delenv("O2345_COLOR_KERNEL", raising=False)
     s = small_scene(V=V, HW=40, D=16) if V != 4 else small_scene()
     d = dev_scene(s, dev, ops)
     blob = d["color_x3_blob"] if mfma == "x3" else (d["color_mfma_blob"] if mfma else d["color_blob"])
