@@ -129,3 +129,23 @@ def export_mesh_ply(path, wt, vol, proj, cam_pos, resolution, scale_mat=None, tr
     verts_idx, tris, rgb, _ = extract_mesh(wt, vol, proj, cam_pos, resolution, return_index_verts=True)
     return mesh_io.export_mesh(path, verts_idx, tris, resolution, scale_mat=scale_mat, trans_mat=trans_mat,
                                vertex_colors=rgb if verts_idx.shape[0] else None)
+
+
+@torch.no_grad()
+def reconstruct_folder(root_dir, name, wt, out_ply, D=96, resolution=256, render_val_image=False):
+    """run.py's reconstruction stage without the reference tree: Zero123-style folder (dataset.SceneFolder) -> coloured mesh (binary PLY in
+    the original frame), optionally the val image of the target view.  Returns dict(vertices, triangles, kept_voxels[, color, depth])."""
+    from . import dataset
+    s = dataset.SceneFolder(root_dir, "export_mesh", specific_dataset_name=name)[0]
+    dev = wt.device
+    T = lambda t: t.to(dev).contiguous().float()
+    vol = build_volume(wt, T(s["images"]), T(s["affine_mats"]), s["partial_vol_origin"].numpy(), D, 2.0 / (D - 1))
+    proj, cam_pos = camera_terms(T(s["intrinsics"]), T(s["w2cs"]))
+    nv, nt = export_mesh_ply(out_ply, wt, vol, proj, cam_pos, resolution, scale_mat=s["scale_mat"], trans_mat=s["trans_mat"])
+    out = {"vertices": nv, "triangles": nt, "kept_voxels": int(vol["n_voxels"])}
+    if render_val_image:
+        r = render(wt, vol, proj, cam_pos, T(s["rays"]["rays_o"]), T(s["rays"]["rays_v"]), float(s["query_near_far"][0]), float(s["query_near_far"][1]),
+                   T(s["query_c2w"][:3, 3]))
+        H, W = int(s["img_wh"][1]), int(s["img_wh"][0])
+        out["color"], out["depth"] = r["color"].view(H, W, 3), r["depth"].view(H, W)
+    return out

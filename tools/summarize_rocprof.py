@@ -1,6 +1,7 @@
 """Turn rocprofv3 output into the small summaries kept under profiles/.
 
   python tools/summarize_rocprof.py stats <dir with *_kernel_stats.csv> <out.md> "<title line>"
+  python tools/summarize_rocprof.py trace <dir with *_kernel_trace.csv> <out.md> "<title line>"      (per launch-size class)
   python tools/summarize_rocprof.py pmc <dir with one sub-directory per --pmc pass> <out.json>
        -> {kernel: {counter: mean value per launch}} for the o2345 kernels, averaged over the launches within 20 % of the largest value
           (the timed full-size launches, not the tiny ones of the setup render)
@@ -27,6 +28,32 @@ def stats(d, out, title):
         o.write(open(f).read())
 
 
+def trace(d, out, title):
+    """Per-kernel rows from the kernel TRACE (not the stats file), one row per launch-size class: persistent kernels launch the same grid for
+    every problem size, so the launches of a kernel are clustered by duration (a new class wherever consecutive sorted durations differ by
+    more than 2.5x) -- a render-size launch and a 0.4 ms vertex-colour launch of the same kernel never share an average."""
+    f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[0]
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    rows = []
+    for k, ds in per.items():
+        ds.sort()
+        grp = [ds[0]]
+        for x in ds[1:]:
+            if x > 2.5 * grp[-1] and x > grp[-1] + 5.0:
+                rows.append((k, grp)); grp = []
+            grp.append(x)
+        rows.append((k, grp))
+    total = sum(sum(g) for _, g in rows)
+    rows.sort(key=lambda r: -sum(r[1]))
+    with open(out, "w") as o:
+        o.write(f"# {title}\n\n(one row per kernel and launch-size class; times in microseconds)\n\n| kernel | launches | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
+        for k, g in rows[:60]:
+            n = k if len(k) <= 90 else k[:87] + "..."
+            o.write(f"| `{n}` | {len(g)} | {sum(g) / 1e3:.3f} | {sum(g) / len(g):.1f} | {g[0]:.1f} | {g[-1]:.1f} | {100 * sum(g) / total:.2f} |\n")
+
+
 def pmc(d, out):
     res = collections.defaultdict(dict)
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
@@ -48,5 +75,7 @@ def pmc(d, out):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "trace":
+        trace(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         pmc(sys.argv[2], sys.argv[3])
