@@ -1,6 +1,8 @@
 """CPU: the MFMA weight-blob packing of csrc/sdf_mlp.hip, checked by emulating the kernel's dataflow in numpy
 (documented lane layouts of v_mfma_f32_32x32x2_f32) against the oracle MLP and its analytic gradient."""
 import numpy as np
+
+import weights_emulators as EMU
 import torch
 
 from oracle import recon as O
@@ -21,7 +23,7 @@ def test_blob_emulation_matches_oracle(pkg):
     rng = np.random.default_rng(0)
     pts = rng.uniform(-1, 1, (29, 3)).astype(np.float32)
     lat = rng.normal(0, 1, (29, 16)).astype(np.float32)
-    y, gpe, glat = pkg.weights.emulate_sdf_blob(blob, pts, lat)
+    y, gpe, glat = EMU.emulate_sdf_blob(blob, pts, lat)
     Wt = {k: torch.from_numpy(v) for k, v in W.items()}
     ref = O.sdf_mlp(torch.from_numpy(pts), torch.from_numpy(lat), Wt).numpy()
     assert np.abs(y - ref).max() < 2e-5
@@ -48,7 +50,7 @@ def test_bf16_blob_emulation(pkg):
     rng = np.random.default_rng(4)
     pts = rng.uniform(-1, 1, (31, 3)).astype(np.float32)
     lat = rng.normal(0, 1, (31, 16)).astype(np.float32)
-    sdf, gpe, glat = Wn.emulate_sdf_blob_bf16(blob, pts, lat)
+    sdf, gpe, glat = EMU.emulate_sdf_blob_bf16(blob, pts, lat)
     q = lambda x: Wn.bf16_to_f32(Wn.bf16_round(np.asarray(x, np.float32))).astype(np.float64)
     sp = lambda a: np.where(a * 100 > 20, a, np.log1p(np.exp(np.minimum(a * 100, 50))) / 100)
     dsp = lambda a: 1 / (1 + np.exp(-np.clip(a * 100, -700, 700)))
@@ -82,7 +84,7 @@ def test_x3_blob_emulation(pkg):
     pts = rng.uniform(-1, 1, (32, 3)).astype(np.float32)
     lat = rng.normal(0, 1, (32, 16)).astype(np.float32)
     lat[:4] *= 1e-3                                          # small operands exercise the f16-subnormal lo halves
-    sdf = Wn.emulate_sdf_blob_x3(blob, pts, lat)
+    sdf = EMU.emulate_sdf_blob_x3(blob, pts, lat)
     w0, w1, w2 = (W[k].astype(np.float64) for k in ("w0", "w1", "w2"))
     sp = lambda a: np.where(a * 100 > 20, a, np.log1p(np.exp(np.minimum(a * 100, 50))) / 100)
     pe = O.embed(torch.from_numpy(pts)).numpy().astype(np.float64)
@@ -129,12 +131,44 @@ def test_color_mfma_blob_emulation_matches_oracle(pkg):
         if P > 1:
             m[0] = False                                     # a point that no view sees
         rf64 = np.concatenate([rf, np.zeros((P, G, 5), np.float32)], -1)
-        got = pkg.weights.emulate_color_mfma(blob, geo, rf64, rd, m.astype(np.float32), G)
+        got = EMU.emulate_color_mfma(blob, geo, rf64, rd, m.astype(np.float32), G)
         ref, _ = O.rendering_network(RW, torch.from_numpy(geo), torch.from_numpy(rf).permute(1, 0, 2), torch.from_numpy(rd).permute(1, 0, 2),
                                      torch.from_numpy(m).permute(1, 0))
         assert np.abs(got - ref.numpy()).max() < 2e-5, G
         # split-f16 instantiation: regrouped blob, activations split as on the device
         xblob = pkg.weights.pack_color_x3_blob(sd)
         assert xblob.size == pkg.weights.CX_BLOB_FLOATS
-        gotx = pkg.weights.emulate_color_mfma(blob, geo, rf64, rd, m.astype(np.float32), G, x3_blob=xblob)
+        gotx = EMU.emulate_color_mfma(blob, geo, rf64, rd, m.astype(np.float32), G, x3_blob=xblob)
         assert np.abs(gotx - got).max() < 5e-6, (G, np.abs(gotx - got).max())
+
+
+def test_shared_rows_matrix_operand_of_color_pts(pkg):
+    """A_S (csrc/color_pts.hip): the view-independent rows of base_fc.0 as an MFMA A operand -- every (block, k slot, lane) entry is the W_S entry
+    of (output neuron 32 b + lane % 32, operand row of slot s in half lane // 32); the split-f16 copy reproduces it to 2^-21."""
+    W = pkg.weights
+    sd = W.init_color_state_dict(5)
+    b32, bx = W.pack_color_mfma_blob(sd), W.pack_color_x3_blob(sd)
+    assert b32.size == W.CM_BLOB_FLOATS and bx.size == W.CX_BLOB_FLOATS
+    off = W.CM_LAYOUT["A_S"][0]
+    A = b32[off:off + 2 * 72 * 64].reshape(2, 72, 64)
+    ws_off = W.CM_LAYOUT["W_S"][0]
+    ws = b32[ws_off:ws_off + 144 * 64].reshape(144, 64)
+    n_checked = 0
+    for b in range(2):
+        for s in range(72):
+            for lane in range(64):
+                i, h = lane & 31, lane >> 5
+                if s < 8:
+                    row = 8 * h + s
+                else:
+                    f = 32 * h + (s - 8) % 32
+                    row = None if f >= 59 else (16 + f if s < 40 else 80 + f)
+                want = 0.0 if row is None else ws[row, 32 * b + i]
+                assert A[b, s, lane] == want
+                n_checked += row is not None
+    assert n_checked == 2 * 32 * (16 + 59 + 59) and np.abs(A).max() > 0
+    sec = bx[W.CX_A_S:W.CX_A_S + 2 * 9 * 512].view(np.float16).reshape(2, 9, 2, 64, 8).astype(np.float32)
+    rec = (sec[:, :, 0] + sec[:, :, 1]).transpose(0, 1, 3, 2).reshape(2, 72, 64)              # [b][k-step][lane][t] -> [b][8 s + t][lane]
+    assert np.abs(rec - A).max() <= 2.0 ** -21 * max(1.0, np.abs(A).max())
+    # the prefix read by k_color_mfma is unchanged by the appended segment
+    assert off == W.CM_LAYOUT["S_SCALAR"][0] + 4 and W.CX_A_S == W.CX_A_END + (off - W.CM_TAIL0)
