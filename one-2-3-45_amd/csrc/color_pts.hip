@@ -47,8 +47,9 @@ __device__ __forceinline__ ViewGeom view_geom(const ColorMArgs& a, int v, float 
 }
 
 // this half's 32 pixel floats of view v at (g.gx, g.gy), bilinear, ATen zero padding, in the log2(e)-scaled domain.
-// (Measured alternatives, all slower on MI355X: branch-free taps 50-59 ms, taps of view v + 1 requested during the network of view v
-// -- one tap, 32 registers, at a time -- 48.4 ms; this form 45.2 ms.  See DESIGN.md section 8.)
+// (Measured alternatives, all slower on MI355X: branch-free taps 50-59 ms; taps of view v + 1 requested during the network of view v
+// -- one tap, 32 registers, at a time -- 48.4 ms; lane octets fetching whole 128-byte half pixels through global_load_lds into a per-wave
+// LDS staging area (8 lines per instruction instead of up to 64) 48.9 ms; this form 44.5-45.2 ms.  See DESIGN.md section 8.)
 __device__ __forceinline__ void gather_now(const ColorMArgs& a, int h, int v, const ViewGeom& g, float (&rf)[32]) {
 #pragma unroll
     for (int c = 0; c < 32; ++c) rf[c] = 0.f;
