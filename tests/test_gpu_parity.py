@@ -344,7 +344,7 @@ def test_render(dev, ops, nrays, precision):
     assert ref["weights_sum"].max() > 0.5, "test scene must contain a surface"
     # (1) sampler stage with identical inputs (one call for all rays: same per-call quirk semantics as the render call above)
     dz, pdf, width = FU.sampler_stage_check(ops, dev, tro, trd, near, far, a, d["maskvol"].reshape(-1), s["D"], chunk=nrays)
-    assert float(dz.max()) < 5e-5 and float((dz / width.clamp(min=1e-9)).max()) < 5e-3, (float(dz.max()), float((dz / width.clamp(min=1e-9)).max()))
+    assert float(dz.max()) < 2e-4 and float((dz / width.clamp(min=1e-9)).max()) < 5e-3, (float(dz.max()), float((dz / width.clamp(min=1e-9)).max()))
     # (2) downstream of the sampler on the HIP path's own sample lists: ALL rays, tight
     z_gpu = out["z_vals"].t().cpu().contiguous()
     core = FU.oracle_core(a, tro, trd, near, far, z_gpu, chunk=nrays)
