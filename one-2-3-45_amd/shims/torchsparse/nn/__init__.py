@@ -18,6 +18,12 @@ def _o():
     return _ops
 
 
+def _require_device(t):
+    """HIP-only: there is no CPU fallback (ops would refuse a CPU tensor anyway; this gives the clearer message)."""
+    if not t.is_cuda:
+        raise RuntimeError("o2345 torchsparse shim: HIP-only (no CPU fallback)")
+
+
 def _level(x):
     """Level descriptor of x's stride: (coords int32 [N,4], index grid, lattice cells/axis)."""
     lv = x.cmaps.get(x.s)
@@ -45,8 +51,7 @@ class Conv3d(nn.Module):
 
     def forward(self, x):
         ops = _o()
-        if not x.F.is_cuda:
-            raise RuntimeError("o2345 torchsparse shim: HIP-only (no CPU fallback)")
+        _require_device(x.F)
         c_in, g_in, cells_in = _level(x)
         k = self.kernel.detach().contiguous()
         f = x.F.detach().contiguous()

@@ -45,7 +45,7 @@ def ref_trainer(monkeypatch, tmp_path):
     """-> (GenericTrainer class of the reference, mirror module namespace); every sys.modules / meta_path change is undone afterwards."""
     import fake_ops
     dropin = importlib.import_module("one-2-3-45_amd.dropin")
-    mine = ("torchsparse", "inplace_abn", "mcubes", "trimesh", "models", "utils", "loss", "cv2", "torchvision", "icecream")
+    mine = ("torchsparse", "inplace_abn", "mcubes", "trimesh", "models", "utils", "loss", "cv2", "torchvision", "icecream", "tsparse")
     saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k.split(".")[0] in mine}
     written = []
 
@@ -202,3 +202,28 @@ def test_val_step_of_the_unchanged_trainer_default_perturb(ref_trainer):
                          color_maps=sample["images"][0], w2cs=sample["w2cs"][0], intrinsics=sample["intrinsics"][0], img_wh=[HW, HW],
                          query_c2w=sample["query_c2w"], if_render_with_grad=False)["color_fine"])
     assert torch.equal(imgs[0], imgs[1]) and not torch.equal(imgs[0], imgs[2])
+
+
+def test_reference_costregnet_on_the_torchsparse_shim(ref_trainer):
+    """INTEGRATION.md's "shims only" level with the REFERENCE's own module code: tsparse/modules.py's SparseCostRegNet (:259-304, built from
+    its BasicSparse{Conv,Deconv}olutionBlock) imports `torchsparse` = our shim (dropin hook) and runs through the shim's Conv3d / BatchNorm /
+    ReLU / SparseTensor.__add__ (kernel-map reuse by the transposed convolutions, coordinate bookkeeping per stride) -- against
+    oracle.sparse_costreg.  CPU stand-ins replace the three ops calls underneath (sparse_downsample, sparse_conv3d, bn_act_rows)."""
+    _, M = ref_trainer
+    import torchsparse
+    from tsparse.modules import SparseCostRegNet
+    from oracle import recon as O
+    from scene_util import costreg_oracle_weights, small_scene
+    assert torchsparse.__name__.startswith("one-2-3-45_amd") or "o2345" in torchsparse.__version__
+    assert "/root/reference" in sys.modules["tsparse.modules"].__file__
+    s = small_scene()
+    net = SparseCostRegNet(d_in=32, d_out=16)
+    sd = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in s["costreg_sd"].items()}
+    miss = net.load_state_dict(sd, strict=False)
+    assert not miss.unexpected_keys and all("running_" in k or "num_batches" in k for k in miss.missing_keys), miss
+    x = torchsparse.SparseTensor(s["vol"].clone(), s["coords"].clone())
+    got = net(x)
+    want, extra = O.sparse_costreg(s["vol"], s["coords"], costreg_oracle_weights(s["costreg_sd"]))
+    assert got.shape == want.shape and float((got - want).abs().max()) < 2e-4 * max(1.0, float(want.abs().max()))
+    for lv, key in zip(extra["levels"][1:], (2, 4, 8)):
+        assert torch.equal(x.cmaps[key][0][:, :3].long(), lv.xyz)
