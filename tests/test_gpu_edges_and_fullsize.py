@@ -102,6 +102,46 @@ def test_zero_points_and_tiny_grids():
     assert float((out["sdf"] == 100).float().mean()) == 1.0          # device-side count 0: nothing evaluated
 
 
+@pytest.mark.parametrize("kernel", ["pts", "tiles"])
+@pytest.mark.parametrize("V", [1, 2, 3, 7])
+def test_colour_kernels_odd_view_counts_and_degenerate_points(V, kernel, monkeypatch):
+    """View counts that are not a power of two (V = 1: mean = the view, variance 0), a single point, a device-side count of zero, points outside
+    the volume / seen by no view (all pooling weights 0 -> uniform softmax over zero colours), in both matrix-core kernels, vs the oracle."""
+    from scene_util import color_t
+    monkeypatch.setenv("O2345_COLOR_KERNEL", kernel)
+    s = small_scene(V=8, HW=40, D=16)
+    sc = s["sc"]
+    t = lambda a: torch.as_tensor(np.asarray(a)).to(dev)
+    sel = list(range(V))
+    proj, cam_pos = pipeline.camera_terms(t(sc["intrinsics"][sel]), t(sc["w2cs"][sel]))
+    cmaps = ops.pack_color_maps(t(s["fmaps"][sel]).contiguous(), t(sc["images"][sel]).contiguous())
+    vol_cl = s["dense"][0].permute(1, 2, 3, 0).contiguous().to(dev)
+    maskvol = s["mask"][0, 0].reshape(-1).contiguous().to(dev)
+    xblob = t(pkg.weights.pack_color_x3_blob(s["color_sd"]))
+    rng = np.random.default_rng(V)
+    pts = torch.from_numpy(rng.uniform(-0.9, 0.9, (77, 3)).astype(np.float32))
+    pts[:5] = torch.tensor([1.5, 0.2, 0.0])                      # outside the volume
+    pts[5:8] = torch.tensor([0.0, 0.0, -0.999])                  # inside the cube, far from what the cameras see
+    qcam = torch.from_numpy(sc["query_c2w"][:3, 3].copy())
+    Kt, w2c = torch.from_numpy(sc["intrinsics"][sel]), torch.from_numpy(sc["w2cs"][sel])
+    geo, rf, rd, vm = O.projector(pts, s["dense"][0], s["mask"][0, 0], torch.from_numpy(s["fmaps"][sel]), torch.from_numpy(sc["images"][sel]), w2c, Kt,
+                                  (s["W"], s["H"]), query_cam=qcam)
+    rgb_ref, nv_ref = O.rendering_network(color_t(s["color_sd"]), geo, rf, rd, vm)
+    rgb, nv = ops.color_points(xblob, vol_cl, maskvol, cmaps, proj, cam_pos, pts.to(dev), query_cam=qcam.to(dev), mfma="x3")
+    assert torch.equal(nv.cpu().float(), nv_ref)
+    assert float((rgb.cpu() - rgb_ref).abs().max()) < 1e-4
+    # one point, and the same through an index list with a device-side count
+    r1, _ = ops.color_points(xblob, vol_cl, maskvol, cmaps, proj, cam_pos, pts[40:41].to(dev).contiguous(), query_cam=qcam.to(dev), mfma="x3")
+    assert float((r1.cpu() - rgb_ref[40:41]).abs().max()) < 1e-4
+    idx = torch.tensor([40, 3, 76], dtype=torch.int32, device=dev)
+    n2 = torch.tensor([2], dtype=torch.int32, device=dev)
+    r2, _ = ops.color_points(xblob, vol_cl, maskvol, cmaps, proj, cam_pos, pts.to(dev), query_cam=qcam.to(dev), index=idx, n_dev=n2, mfma="x3")
+    assert float((r2[[40, 3]].cpu() - rgb_ref[[40, 3]]).abs().max()) < 1e-4 and float(r2[76].abs().sum()) == 0      # third list entry not evaluated
+    n0 = torch.zeros(1, dtype=torch.int32, device=dev)
+    r0, _ = ops.color_points(xblob, vol_cl, maskvol, cmaps, proj, cam_pos, pts.to(dev), query_cam=qcam.to(dev), index=idx, n_dev=n0, mfma="x3")
+    assert float(r0.abs().sum()) == 0
+
+
 # ------------------------------------------------------------------------------------------------- full-size properties
 @pytest.fixture(scope="module")
 def full():
