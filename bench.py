@@ -351,6 +351,8 @@ def main():
     ap.add_argument("--same-scene", action="store_true", help="re-reconstruct one scene every step (round-1 behaviour; A/B knob)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for the CPU plumbing test)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous + sharding only, no GPU work (CPU plumbing test)")
+    ap.add_argument("--share-gpu", action="store_true", help="FUNCTIONAL TEST ONLY: ranks may share a device (rank r on cuda:r mod count; use with "
+                                                             "--backend gloo, RCCL refuses duplicate devices).  The number it prints is not a scaling measurement")
     ap.add_argument("--precision", choices=config.PRECISIONS, default=config.PRECISION,
                     help="network kernels: f16x3 (default; split-f16 MFMA, fp32-class accuracy), fp32 (exact fp32 MFMA), bf16 (SDF throughput mode)")
     a = ap.parse_args()
@@ -370,11 +372,13 @@ def main():
         sharding.shutdown()
         return
     assert torch.cuda.is_available(), "bench.py needs a GPU (the reconstruction path has no CPU fallback)"
+    if a.share_gpu:
+        local = local % torch.cuda.device_count()
     if local >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} device(s) are visible")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:                                            # every rank on its own GPU
+    if world > 1 and not a.share_gpu:                        # every rank on its own GPU
         ids = [None] * world
         torch.distributed.all_gather_object(ids, (os.uname().nodename, local))
         assert len(set(ids)) == world, f"ranks share a device: {ids}"
@@ -432,6 +436,7 @@ def main():
             "metric": "rays/sec + mesh-extract wall-clock per scene (8x256^2 views, 128^3 vol)", "value": world * n_rays / (ms_step * 1e-3),
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            **({"shared_gpu_functional_run": True} if a.share_gpu else {}),
             "config": {"workload": f"BASELINE config 2: 1 scene/GPU/step ({'the same scene' if a.same_scene else 'a different seeded scene'} every step), "
                                    f"{a.views} views 256x256, {a.vol}^3 volume, "
                                    f"{n_rays} rays (64+64 samples), mesh grid {a.mesh_res}^3; whole scene pass per step",

@@ -34,10 +34,15 @@ def barrier(device=None):
         torch.cuda.synchronize(device)
 
 
+def _reduce_device(device):
+    """RCCL reduces device tensors, gloo (CPU tests, shared-GPU functional runs) host tensors."""
+    return device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+
+
 def max_over_ranks(value, device=None):
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_reduce_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -45,7 +50,7 @@ def max_over_ranks(value, device=None):
 def sum_over_ranks(value, device=None):
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_reduce_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 

@@ -13,8 +13,7 @@ os.environ["O2345_COLOR_KERNEL"] = "tiles"
 out = pipeline.render(wt, vol, inp["proj"], inp["cam_pos"], inp["rays_o"], inp["rays_d"], inp["near"], inp["far"], inp["qcam"])
 idx = bench.render_order_index(out["pm"])
 pts = (inp["rays_o"][None] + inp["rays_d"][None] * out["mid_z"][..., None]).reshape(-1, 3).contiguous()
-for env in ({"O2345_COLOR_KERNEL": "tiles"}, {"O2345_COLOR_KERNEL": "pts"}, {"O2345_COLOR_KERNEL": "pts", "O2345_COLOR_DBG": "1"}):
-    os.environ.pop("O2345_COLOR_DBG", None)
+for env in ({"O2345_COLOR_KERNEL": "tiles"}, {"O2345_COLOR_KERNEL": "pts"}):
     os.environ.update(env)
     ops.color_points(wt.color_xblob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], inp["proj"], inp["cam_pos"], pts, query_cam=inp["qcam"], index=idx, want_nviews=False, mfma="x3")
     torch.cuda.synchronize()
