@@ -42,6 +42,17 @@ int o2345_costvol_gather(const float* feats_nhwc, const float* proj, int V, int 
                          float voxel_size, const float* origin_host, const uint8_t* cnt, const int32_t* coords,
                          int n_rows, float* out_rows, void* stream);
 int o2345_nchw_to_nhwc(const float* in, float* out, int V, int C, int H, int W, void* stream);
+
+/* ---- feature pyramid glue of FeatureNet (replaces the ATen kernels between its convolutions; ABI 1.2) ----------------------------------------
+ * fpn_level: out [V,32,H,W] = 1x1 conv (weight [32,c_in], bias [32]) of fine [V,c_in,H,W] + bilinear x2 up-sampling (align_corners = True) of
+ *   coarse [V,32,H/2,W/2]   (models/featurenet.py:73-76, 85-86: _upsample_add(feat, lat(conv))); c_in = 8 or 16.
+ * pyramid_pack: the fused pyramid of models/trainer_generic.py:1117-1123 = [x4 up-sampled f2 (32) | x2 up-sampled s1 (16) | s0 (8)], written once:
+ *   fmaps_nchw [V,56,H,W] (optional, may be NULL) and cmaps_nhwc64 [V,H,W,64] = rgb (3) | those 56 features | 5 zeros (the map the colour kernels
+ *   gather from; replaces o2345_pack_color_maps on this path). */
+int o2345_fpn_level(const float* fine, int c_in, const float* coarse, const float* weight, const float* bias, int V, int H, int W,
+                    float* out, void* stream);
+int o2345_pyramid_pack(const float* f2, const float* s1, const float* s0, const float* rgb, int V, int H, int W, float* fmaps_nchw,
+                       float* cmaps_nhwc64, void* stream);
 /* lod > 0 (sparse_sdf_network.py:335-357): the same two passes for an explicit voxel list coords [n,4] (x,y,z,b) in arbitrary
  * order; cnt / cnt_row are per LIST ROW.  build_index_grid makes the dense row lookup of such a list (cells of size ts). */
 int o2345_visible_count_list(const float* proj, int V, int H, int W, float voxel_size, const float* origin_host,

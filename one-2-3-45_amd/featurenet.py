@@ -63,14 +63,16 @@ class FeatureNet(nn.Module):
         c0 = self.conv0(x)
         c1 = self.conv1(c0)
         c2 = self.conv2(c1)
-        f2 = self.toplayer(c2)
-        f1 = self._up_add(f2, self.lat1(c1))
-        f0 = self._up_add(f1, self.lat0(c0))
+        f2 = self.toplayer(c2).contiguous()
+        # top-down path: lateral 1x1 convolution + x2 bilinear up-sampling + add, one HIP kernel per level (csrc/featmaps.hip)
+        f1 = ops.fpn_level(c1.contiguous(), f2, self.lat1.weight.detach(), self.lat1.bias.detach())
+        f0 = ops.fpn_level(c0.contiguous(), f1, self.lat0.weight.detach(), self.lat0.bias.detach())
         return [f2, self.smooth1(f1), self.smooth0(f0)]
 
 
-def fused_pyramid(extractor, imgs):
-    """trainer_generic.py:1104-1125: [V,3,H,W] -> [V,56,H,W]."""
-    f2, f1, f0 = extractor(imgs)
-    return torch.cat([F.interpolate(f2, scale_factor=4, mode="bilinear", align_corners=True),
-                      F.interpolate(f1, scale_factor=2, mode="bilinear", align_corners=True), f0], dim=1)
+def fused_pyramid(extractor, imgs, want_cmaps=False):
+    """trainer_generic.py:1104-1125: [V,3,H,W] -> fused pyramid [V,56,H,W] (+ the channel-last colour map [V,H,W,64] = rgb | features | pad when
+    want_cmaps): both written by ONE kernel (csrc/featmaps.hip) instead of two F.interpolate, a cat and a re-layout pass."""
+    f2, s1, s0 = extractor(imgs)
+    fm, cm = ops.pyramid_pack(f2.contiguous(), s1.contiguous(), s0.contiguous(), imgs.contiguous().float())
+    return (fm, cm) if want_cmaps else fm

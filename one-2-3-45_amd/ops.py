@@ -81,6 +81,29 @@ def nchw_to_nhwc(x):
 
 
 @_on_device
+def fpn_level(fine, coarse, weight, bias):
+    """FeatureNet._upsample_add(coarse, lateral_1x1(fine)) in one kernel: fine [V,C,H,W] (C = 8 | 16), coarse [V,32,H/2,W/2] -> [V,32,H,W]."""
+    V, C, H, W = fine.shape
+    if tuple(coarse.shape) != (V, 32, H // 2, W // 2):
+        raise ValueError(f"fpn_level: coarse map must be [V,32,H/2,W/2], got {tuple(coarse.shape)} for fine {tuple(fine.shape)}")
+    out = torch.empty(V, 32, H, W, dtype=torch.float32, device=fine.device)
+    check(_lib.lib().o2345_fpn_level(_p(fine), C, _p(coarse), _p(weight.reshape(32, C).contiguous()), _p(bias), V, H, W, _p(out), _stream()), "fpn_level")
+    return out
+
+
+@_on_device
+def pyramid_pack(f2, s1, s0, rgb, want_nchw=True):
+    """Fused pyramid -> (fmaps [V,56,H,W] or None, cmaps [V,H,W,64] = rgb | 56 features | pad)."""
+    V, _, H, W = s0.shape
+    if tuple(f2.shape) != (V, 32, H // 4, W // 4) or tuple(s1.shape) != (V, 16, H // 2, W // 2) or tuple(rgb.shape) != (V, 3, H, W) or s0.shape[1] != 8:
+        raise ValueError("pyramid_pack: expected f2 [V,32,H/4,W/4], s1 [V,16,H/2,W/2], s0 [V,8,H,W], rgb [V,3,H,W]")
+    fm = torch.empty(V, 56, H, W, dtype=torch.float32, device=s0.device) if want_nchw else None
+    cm = torch.empty(V, H, W, 64, dtype=torch.float32, device=s0.device)
+    check(_lib.lib().o2345_pyramid_pack(_p(f2), _p(s1), _p(s0), _p(rgb), V, H, W, _p(fm), _p(cm), _stream()), "pyramid_pack")
+    return fm, cm
+
+
+@_on_device
 def costvol_index(proj, V, H, W, dims, voxel_size, origin, min_views=1):
     """-> cnt u8 [D^3], row_of_voxel i32 [D^3], coords i32 [N,4] (x,y,z,b), N (python int; one 4-byte D2H read)."""
     L = _lib.lib()

@@ -65,15 +65,17 @@ def build_volume(wt, imgs, affine_mats, origin, D, voxel_size, fmaps=None):
     """imgs [V,3,H,W] cuda -> scene dict (dense latent volume, occupancy, colour maps...) -- steps (a),(b) of 3.2.
     ``fmaps`` [V,56,H,W] may be supplied to skip FeatureNet."""
     V, _, H, W = imgs.shape
+    cmaps = None
     if fmaps is None:
-        fmaps = fused_pyramid(wt.featurenet, imgs).contiguous()                # [V,56,H,W]  (MIOpen)
+        fmaps, cmaps = fused_pyramid(wt.featurenet, imgs, want_cmaps=True)     # [V,56,H,W] + [V,H,W,64]: MIOpen convs, HIP ABN / FPN / pyramid kernels
     pre = wt.compress.conv(fmaps).contiguous()                                 # Conv3x3 56->16 (MIOpen)
     _, feats_nhwc = wt.compress.bn(pre, want_nhwc=True)                        # fused ABN + re-layout (HIP)
     cnt, row, coords, n = ops.costvol_index(affine_mats, V, H, W, (D, D, D), voxel_size, origin)
     rows = ops.costvol_gather(feats_nhwc, affine_mats, (D, D, D), voxel_size, origin, cnt, coords)
     rows16 = wt.costreg.forward(rows, coords, row, (D, D, D))
     vol_cl, vol_cf, mask = ops.scatter_dense(rows16, row, (D, D, D), want_cf=False)
-    cmaps = ops.pack_color_maps(fmaps, imgs.contiguous())
+    if cmaps is None:
+        cmaps = ops.pack_color_maps(fmaps, imgs.contiguous())
     return dict(vol_cl=vol_cl, maskvol=mask.view(-1), cmaps=cmaps, n_voxels=n, rows16=rows16, fmaps=fmaps, rows=rows, coords=coords,
                 row_of_voxel=row, cnt=cnt, feats_nhwc=feats_nhwc)
 

@@ -80,6 +80,15 @@ def scatter_dense(rows, row_of_voxel, dims, want_cf=True):
     return cl, cf, v.float().view(1, 1, dx, dy, dz)
 
 
+def fpn_level(fine, coarse, weight, bias):
+    return F.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True) + F.conv2d(fine, weight.reshape(32, -1, 1, 1), bias)
+
+
+def pyramid_pack(f2, s1, s0, rgb, want_nchw=True):
+    fm = torch.cat([F.interpolate(f2, scale_factor=4, mode="bilinear", align_corners=True), F.interpolate(s1, scale_factor=2, mode="bilinear", align_corners=True), s0], 1)
+    return (fm if want_nchw else None), pack_color_maps(fm, rgb)
+
+
 def sparse_downsample(coords, ts, fine_cells):
     """-> (index grid of the coarse level, coarse coords int32 [n,4], n, cells per axis) -- oracle.downsample_coords on the lattice ops uses."""
     nc = tuple((int(c) + 1) // 2 + 1 for c in fine_cells)
@@ -244,7 +253,7 @@ def install(monkeypatch):
     costreg = importlib.import_module("one-2-3-45_amd.costreg")
     featurenet = importlib.import_module("one-2-3-45_amd.featurenet")
     for name in ("costvol_index", "costvol_gather", "visible_count_list", "costvol_gather_list", "build_index_grid", "scatter_dense", "sdf_mlp",
-                 "pack_color_maps", "color_points", "render_rays", "marching_cubes", "prune_dilate", "sparse_downsample", "sparse_conv3d", "bn_act_rows"):
+                 "pack_color_maps", "color_points", "render_rays", "marching_cubes", "prune_dilate", "sparse_downsample", "sparse_conv3d", "bn_act_rows", "fpn_level", "pyramid_pack"):
         monkeypatch.setattr(ops, name, globals()[name])
     spnn = importlib.import_module("one-2-3-45_amd.shims.torchsparse.nn")
     monkeypatch.setattr(spnn, "_require_device", lambda t: None)

@@ -90,6 +90,33 @@ def main_perturb(seed=1234):
           float(np.abs(out["ren_color_fine"] - g0["ren_color_fine"]).max()))
 
 
+def main_featurenet(seed=21):
+    """tests/golden/ref_featurenet.npz: the reference's FeatureNet (models/featurenet.py:40-91, InPlaceABN = the functional stand-in of
+    oracle/ref_import.py) and the fused pyramid of GenericTrainer.obtain_pyramid_feature_maps (trainer_generic.py:1117-1123) on seeded images."""
+    torch.set_grad_enabled(False)
+    import torch.nn.functional as F
+    R = RI.load()
+    from models.featurenet import FeatureNet
+    torch.manual_seed(seed)
+    net = FeatureNet()
+    g = torch.Generator().manual_seed(seed)
+    for m in net.modules():
+        if type(m).__name__ == "InPlaceABN":
+            m.weight.data = (1 + 0.2 * torch.randn(m.weight.shape, generator=g)) * torch.where(torch.rand(m.weight.shape, generator=g) < 0.2, -1.0, 1.0)
+            m.bias.data = 0.1 * torch.randn(m.bias.shape, generator=g)
+    imgs = torch.rand(2, 3, 48, 64, generator=g)
+    f2, s1, s0 = net(imgs)
+    fused = torch.cat([F.interpolate(f2, scale_factor=4, mode="bilinear", align_corners=True),
+                       F.interpolate(s1, scale_factor=2, mode="bilinear", align_corners=True), s0], dim=1)        # trainer_generic.py:1117-1123
+    out = {"imgs": imgs.numpy(), "f2": f2.numpy(), "s1": s1.numpy(), "s0": s0.numpy(), "fused": fused.numpy()}
+    for k, v in net.state_dict().items():
+        if "running_" not in k and "num_batches" not in k:
+            out["w:" + k] = v.numpy()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_featurenet.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; fused", tuple(fused.shape), "max", float(fused.abs().max()))
+
+
 def main():
     torch.set_grad_enabled(False)
     cfg = CFG
@@ -174,4 +201,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main_perturb() if "--perturb" in sys.argv else main()
+    main_perturb() if "--perturb" in sys.argv else (main_featurenet() if "--featurenet" in sys.argv else main())
