@@ -267,7 +267,7 @@ def test_fullsize_oracle_parity(full, precision):
     print(f"[{precision}] {len(dev_rays)} of {len(sel)} rays deviate by > 1e-4 in colour; ray ids {sel[dev_rays.numpy()].tolist()}; "
           f"their sample lists differ by {zerr[dev_rays].min().item() if len(dev_rays) else 0:.2e} .. {zerr[dev_rays].max().item() if len(dev_rays) else 0:.2e}")
     assert bool((zerr[dev_rays] > 1e-6).all())                       # every deviation is attributable to the sample lists (2 is tight for all rays)
-    assert float(zerr.max()) < (far - near) / 63                     # never more than one coarse section
+    assert float(zerr.max()) <= 1.001 * (far - near) / 63            # never more than one coarse section (a relocated sample shifts the sorted list by one)
     ce, _ = FU.oracle_self_sensitivity(fu, sel, ref)
     q = lambda t, x: float(torch.quantile(t.flatten(), x))
     for x in (0.5, 0.9, 0.99):
