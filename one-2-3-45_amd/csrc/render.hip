@@ -117,10 +117,14 @@ __global__ __launch_bounds__(256) void k_ray_finalize(RayGeom g, const float* __
             const float m = mask_at(maskvol, D, x, y, w);
             dists[p] = d; mid_z[p] = mz; pm[p] = m;
             pts[3 * p] = x; pts[3 * p + 1] = y; pts[3 * p + 2] = w;
-            sdf[p] = 100.f;                                     // (:231)
-            grad[3 * p] = 0.f; grad[3 * p + 1] = 0.f; grad[3 * p + 2] = 0.f;
-            rgb[3 * p] = 0.f; rgb[3 * p + 1] = 0.f; rgb[3 * p + 2] = 0.f;
             if (m > 0.f) { bits.w[s >> 5] |= 1u << (s & 31); ++cnt; }
+            else {
+                // the reference's defaults (:231: sdf = 100, gradients = colours = 0).  Occupied points are ALWAYS overwritten by the network kernels that
+                // consume the list (o2345_render_rays evaluates every list entry), so only unoccupied points need them: 28 bytes less per occupied point
+                sdf[p] = 100.f;
+                grad[3 * p] = 0.f; grad[3 * p + 1] = 0.f; grad[3 * p + 2] = 0.f;
+                rgb[3 * p] = 0.f; rgb[3 * p + 1] = 0.f; rgb[3 * p + 2] = 0.f;
+            }
         }
     }
     append_wave(bits, S, cnt, g.R, r, list, count);
