@@ -3,7 +3,7 @@
 
 A "step" = one full pass of the hot path over one synthetic scene of BASELINE config 2
 (8 views x 256^2, 128^3 volume, 512 x 512 rays, mesh extraction on a 256^3 grid):
-   FeatureNet + compress layer (MIOpen convs, HIP ABN) -> cost volume (HIP) -> sparse CNN (HIP) -> dense volume ->
+   FeatureNet + compress layer (HIP convolutions on the matrix cores, ABN folded in) -> cost volume (HIP) -> sparse CNN (HIP) -> dense volume ->
    render 262,144 rays (HIP: hierarchical sampling, SDF / colour networks, compositing) ->
    SDF grid + marching cubes + vertex colours (HIP).
 Inputs (images, cameras, weights) are resident in HBM before the timed region.  `value` = rays rendered by all ranks /

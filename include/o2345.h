@@ -53,6 +53,32 @@ int o2345_fpn_level(const float* fine, int c_in, const float* coarse, const floa
                     float* out, void* stream);
 int o2345_pyramid_pack(const float* f2, const float* s1, const float* s0, const float* rgb, int V, int H, int W, float* fmaps_nchw,
                        float* cmaps_nhwc64, void* stream);
+/* ---- the convolutions of FeatureNet and of the compress layer (ABI 1.3; replace nn.Conv2d + InPlaceABN pairs: models/featurenet.py:12-22
+ * ConvBnReLU, :40-66 FeatureNet, models/sparse_sdf_network.py:171-173 compress_layer) ---------------------------------------------------------
+ * conv2d: out [V,cout,Ho,Wo] = conv2d(act(in), w) (+ bias), padding k / 2, stride 1 or 2; w_packed = [cin][k][k][cout] (conv2d_pack_weights of an
+ *   nn.Conv2d weight [cout,cin,k,k]).  in_scale_shift [2*cin] (may be NULL): the InPlaceABN of the PRODUCER of `in` is applied while `in` is read,
+ *   act(x) = leaky_relu(x * scale + shift, slope) -- the activated tensor is never stored.  out_scale_shift [2*cout] (may be NULL): batch
+ *   statistics of `out` over (V,Ho,Wo) -> this layer's own (scale, shift) = ((|gamma| + eps) / sqrt(var + eps), beta - mean * scale) for the
+ *   consumer to apply (needs gamma, beta and a workspace of conv2d_workspace_bytes).  Shapes: the ten (cin, cout, k, stride) of FeatureNet and
+ *   the compress layer; anything else is an error.
+ * fpn_level_act: fpn_level whose `fine` input is a raw convolution output with its (scale, shift) applied on load.
+ * scale_shift_act: y = leaky_relu(x * scale + shift) for x [V,C,H,W], written as NCHW and / or channel-last NHWC (C = 8, 16, 32). */
+int o2345_conv2d_pack_weights(const float* w_oihw, int cout, int cin, int k, float* packed, void* stream);
+size_t o2345_conv2d_workspace_bytes(int V, int cout, int Ho, int Wo);
+int o2345_conv2d(const float* in, int V, int cin, int Hi, int Wi, const float* in_scale_shift, float slope, const float* w_packed,
+                 const float* bias, int cout, int k, int stride, float* out, const float* gamma, const float* beta, float eps, int abs_gamma,
+                 float* out_scale_shift, void* workspace, size_t workspace_bytes, void* stream);
+/* the same convolution on the matrix cores (split-f16 operands, fp32 accumulate: the default numerical mode); cin <= 64, cout <= 32;
+ * w_packed_x3 [conv2d_x3_weight_floats] from conv2d_pack_weights_x3 */
+size_t o2345_conv2d_x3_weight_floats(int cin, int k);
+int o2345_conv2d_pack_weights_x3(const float* w_oihw, int cout, int cin, int k, float* packed, void* stream);
+int o2345_conv2d_x3(const float* in, int V, int cin, int Hi, int Wi, const float* in_scale_shift, float slope, const float* w_packed_x3,
+                    const float* bias, int cout, int k, int stride, float* out, const float* gamma, const float* beta, float eps, int abs_gamma,
+                    float* out_scale_shift, void* workspace, size_t workspace_bytes, void* stream);
+int o2345_fpn_level_act(const float* fine, const float* fine_scale_shift, float slope, int c_in, const float* coarse, const float* weight,
+                        const float* bias, int V, int H, int W, float* out, void* stream);
+int o2345_scale_shift_act(const float* x, int V, int C, int H, int W, const float* scale_shift, float slope, float* y_nchw, float* y_nhwc,
+                          void* stream);
 /* lod > 0 (sparse_sdf_network.py:335-357): the same two passes for an explicit voxel list coords [n,4] (x,y,z,b) in arbitrary
  * order; cnt / cnt_row are per LIST ROW.  build_index_grid makes the dense row lookup of such a list (cells of size ts). */
 int o2345_visible_count_list(const float* proj, int V, int H, int W, float voxel_size, const float* origin_host,

@@ -33,7 +33,7 @@ __device__ __forceinline__ float bilerp(const float* __restrict__ plane, int w_i
 template <int CIN>
 __global__ __launch_bounds__(256) void k_fpn_level(const float* __restrict__ fine /*[V,CIN,H,W]*/, const float* __restrict__ coarse /*[V,32,H/2,W/2]*/,
                                                     const float* __restrict__ w /*[32,CIN]*/, const float* __restrict__ bias /*[32]*/, int H, int W,
-                                                    float* __restrict__ out /*[V,32,H,W]*/) {
+                                                    float* __restrict__ out /*[V,32,H,W]*/, const float* __restrict__ fine_ss /*[2*CIN] or null*/, float slope) {
     __shared__ float sw[32 * CIN + 32];
     for (int i = threadIdx.x; i < 32 * CIN + 32; i += 256) sw[i] = i < 32 * CIN ? w[i] : bias[i - 32 * CIN];
     __syncthreads();
@@ -42,7 +42,14 @@ __global__ __launch_bounds__(256) void k_fpn_level(const float* __restrict__ fin
     const int y = p / W, x = p % W, hc = H / 2, wc = W / 2;
     float in[CIN];
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) in[c] = fine[((size_t)v * CIN + c) * H * W + p];
+    for (int c = 0; c < CIN; ++c) {
+        float t = fine[((size_t)v * CIN + c) * H * W + p];
+        if (fine_ss) {                                      // `fine` is a raw convolution output: its InPlaceABN is applied here (csrc/convnet.hip)
+            t = t * fine_ss[c] + fine_ss[CIN + c];
+            t = t >= 0.f ? t : t * slope;
+        }
+        in[c] = t;
+    }
     const Lerp ly = up_coord(y, hc, H), lx = up_coord(x, wc, W);
     const float* cbase = coarse + (size_t)v * 32 * hc * wc;
     for (int o = 0; o < 32; ++o) {
@@ -96,16 +103,21 @@ using namespace o2345;
 
 extern "C" {
 
-int o2345_fpn_level(const float* fine, int c_in, const float* coarse, const float* weight, const float* bias, int V, int H, int W, float* out,
-                    void* stream) {
+int o2345_fpn_level_act(const float* fine, const float* fine_scale_shift, float slope, int c_in, const float* coarse, const float* weight,
+                        const float* bias, int V, int H, int W, float* out, void* stream) {
     O2345_REQUIRE(fine && coarse && weight && bias && out, "fpn_level: null pointer");
     O2345_REQUIRE(H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2 && V >= 1, "fpn_level: even map sizes required (got %d x %d)", H, W);
     const dim3 grid(cdiv((long long)H * W, 256), V);
     hipStream_t s = (hipStream_t)stream;
-    if (c_in == 8) hipLaunchKernelGGL(k_fpn_level<8>, grid, dim3(256), 0, s, fine, coarse, weight, bias, H, W, out);
-    else if (c_in == 16) hipLaunchKernelGGL(k_fpn_level<16>, grid, dim3(256), 0, s, fine, coarse, weight, bias, H, W, out);
+    if (c_in == 8) hipLaunchKernelGGL(k_fpn_level<8>, grid, dim3(256), 0, s, fine, coarse, weight, bias, H, W, out, fine_scale_shift, slope);
+    else if (c_in == 16) hipLaunchKernelGGL(k_fpn_level<16>, grid, dim3(256), 0, s, fine, coarse, weight, bias, H, W, out, fine_scale_shift, slope);
     else O2345_REQUIRE(false, "fpn_level: FeatureNet's lateral layers have 8 or 16 input channels (got %d)", c_in);
     return check_launch("fpn_level");
+}
+
+int o2345_fpn_level(const float* fine, int c_in, const float* coarse, const float* weight, const float* bias, int V, int H, int W, float* out,
+                    void* stream) {
+    return o2345_fpn_level_act(fine, nullptr, 0.f, c_in, coarse, weight, bias, V, H, W, out, stream);
 }
 
 int o2345_pyramid_pack(const float* f2, const float* s1, const float* s0, const float* rgb, int V, int H, int W, float* fmaps_nchw, float* cmaps_nhwc64,

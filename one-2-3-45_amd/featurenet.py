@@ -1,11 +1,21 @@
-"""FeatureNet + fused pyramid maps on stock PyTorch-ROCm (MIOpen convolutions), with InPlaceABN replaced by the HIP
-batch-statistics op.  Mirrors models/featurenet.py:12-91 and trainer_generic.py:1104-1125; state-dict keys are
-identical to the reference's (``conv0.0.conv.weight``, ``conv0.0.bn.{weight,bias,running_mean,running_var}``, ...)."""
+"""FeatureNet + fused pyramid maps, all HIP (csrc/convnet.hip direct convolutions with InPlaceABN folded into producer / consumer,
+csrc/featmaps.hip top-down path and pyramid).  Mirrors models/featurenet.py:12-91 and trainer_generic.py:1104-1125; the nn.Conv2d /
+InPlaceABN modules only hold the parameters, so state-dict keys are identical to the reference's (``conv0.0.conv.weight``,
+``conv0.0.bn.{weight,bias,running_mean,running_var}``, ...)."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
+
+
+def packed_weight(conv):
+    """The kernel packing of an nn.Conv2d's weight, cached ON the module that owns the parameter (re-packed when the parameter object, its
+    version or its storage changes -- load_state_dict, .to(device), an optimiser step)."""
+    w = conv.weight
+    key = (id(w), w._version, w.data_ptr(), str(w.device), ops.conv_x3())
+    if getattr(conv, "_o2345_packed_key", None) != key:
+        conv._o2345_packed, conv._o2345_packed_key = ops.conv2d_pack(w.detach()), key
+    return conv._o2345_packed
 
 
 class InPlaceABN(nn.Module):
@@ -34,13 +44,31 @@ class InPlaceABN(nn.Module):
 
 
 class ConvBnReLU(nn.Module):
+    """nn.Conv2d (no bias) + InPlaceABN as ONE direct HIP convolution (csrc/convnet.hip): the kernel writes the raw convolution output and
+    reduces its batch statistics; the normalisation + leaky ReLU is applied by whoever reads that output next (``raw``), or by one extra
+    pass when a caller wants the activated tensor itself (``forward`` / ``forward_nhwc``)."""
+
     def __init__(self, cin, cout, k=3, stride=1, pad=1):
         super().__init__()
+        if pad != k // 2:
+            raise NotImplementedError("o2345 ConvBnReLU: padding = kernel // 2 (as everywhere in the reference)")
         self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False)
         self.bn = InPlaceABN(cout)
 
+    def raw(self, x, in_scale_shift=None):
+        """-> (raw conv output, this layer's ABN (scale | shift)); ``in_scale_shift``: x is itself a raw output to be activated on load."""
+        bn = self.bn                                      # ops.conv2d raises for CPU tensors: there is no CPU fallback
+        return ops.conv2d(x.contiguous().float(), self.conv.weight.detach(), None, self.conv.stride[0], in_scale_shift, bn.slope,
+                          bn=(bn.weight.detach(), bn.bias.detach(), bn.eps, bn.abs_gamma), packed=packed_weight(self.conv))
+
     def forward(self, x):
-        return self.bn(self.conv(x))
+        r, ss = self.raw(x)
+        return ops.scale_shift_act(r, ss, self.bn.slope)[0]
+
+    def forward_nhwc(self, x):
+        """The activated output as a channel-last map [V,H,W,C] (what the cost-volume gather reads)."""
+        r, ss = self.raw(x)
+        return ops.scale_shift_act(r, ss, self.bn.slope, want_nchw=False, want_nhwc=True)[1]
 
 
 class FeatureNet(nn.Module):
@@ -55,19 +83,24 @@ class FeatureNet(nn.Module):
         self.smooth1 = nn.Conv2d(32, 16, 3, padding=1)
         self.smooth0 = nn.Conv2d(32, 8, 3, padding=1)
 
-    @staticmethod
-    def _up_add(x, y):
-        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) + y
-
     def forward(self, x):
-        c0 = self.conv0(x)
-        c1 = self.conv1(c0)
-        c2 = self.conv2(c1)
-        f2 = self.toplayer(c2).contiguous()
-        # top-down path: lateral 1x1 convolution + x2 bilinear up-sampling + add, one HIP kernel per level (csrc/featmaps.hip)
-        f1 = ops.fpn_level(c1.contiguous(), f2, self.lat1.weight.detach(), self.lat1.bias.detach())
-        f0 = ops.fpn_level(c0.contiguous(), f1, self.lat0.weight.detach(), self.lat0.bias.detach())
-        return [f2, self.smooth1(f1), self.smooth0(f0)]
+        """[V,3,H,W] -> [f2 (32 @ H/4), smooth1 (16 @ H/2), smooth0 (8 @ H)] (featurenet.py:68-91).  25 HIP launches, no library call: every
+        convolution hands its raw output + ABN (scale | shift) to the next kernel, which normalises and activates on load."""
+        r, ss = x, None
+        raws = []
+        for seq in (self.conv0, self.conv1, self.conv2):
+            for blk in seq:
+                r, ss = blk.raw(r, ss)
+            raws.append((r, ss))
+        (c0, ss0), (c1, ss1), (c2, ss2) = raws
+        slope = self.conv0[0].bn.slope
+        f2, _ = ops.conv2d(c2, self.toplayer.weight.detach(), self.toplayer.bias.detach(), 1, ss2, slope, packed=packed_weight(self.toplayer))
+        # top-down path: lateral 1x1 convolution + x2 bilinear up-sampling + add, one kernel per level (csrc/featmaps.hip)
+        f1 = ops.fpn_level(c1, f2, self.lat1.weight.detach(), self.lat1.bias.detach(), ss1, slope)
+        f0 = ops.fpn_level(c0, f1, self.lat0.weight.detach(), self.lat0.bias.detach(), ss0, slope)
+        s1, _ = ops.conv2d(f1, self.smooth1.weight.detach(), self.smooth1.bias.detach(), packed=packed_weight(self.smooth1))
+        s0, _ = ops.conv2d(f0, self.smooth0.weight.detach(), self.smooth0.bias.detach(), packed=packed_weight(self.smooth0))
+        return [f2, s1, s0]
 
 
 def fused_pyramid(extractor, imgs, want_cmaps=False):

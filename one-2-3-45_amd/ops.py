@@ -80,14 +80,78 @@ def nchw_to_nhwc(x):
     return out
 
 
+def conv_x3(precision=None):
+    """True when the convolutions run on the matrix cores (split-f16 form, the default numerical mode), False for the strict fp32 VALU kernels."""
+    return config.color_precision(precision) == "f16x3"
+
+
 @_on_device
-def fpn_level(fine, coarse, weight, bias):
-    """FeatureNet._upsample_add(coarse, lateral_1x1(fine)) in one kernel: fine [V,C,H,W] (C = 8 | 16), coarse [V,32,H/2,W/2] -> [V,32,H,W]."""
+def conv2d_pack(weight, precision=None):
+    """nn.Conv2d weight [cout,cin,k,k] -> the operand packing of the convolution kernels for the numerical mode in force (one tiny launch; callers
+    that own the parameter cache the result, see featurenet.packed_weight): split-f16 MFMA A operands [tap][cin/16][hi|lo][64 lanes][8 f16]
+    or, in fp32 mode, [cin][k][k][cout] for the scalar-load VALU kernels."""
+    cout, cin, k, k2 = weight.shape
+    if k != k2:
+        raise ValueError("conv2d: square kernels only")
+    L = _lib.lib()
+    if conv_x3(precision):
+        t = torch.empty(L.o2345_conv2d_x3_weight_floats(cin, k), dtype=torch.float32, device=weight.device)
+        check(L.o2345_conv2d_pack_weights_x3(_p(_f(weight)), cout, cin, k, _p(t), _stream()), "conv2d_pack_weights_x3")
+    else:
+        t = torch.empty(cin * k * k * cout, dtype=torch.float32, device=weight.device)
+        check(L.o2345_conv2d_pack_weights(_p(_f(weight)), cout, cin, k, _p(t), _stream()), "conv2d_pack_weights")
+    return t
+
+
+@_on_device
+def conv2d(x, weight, bias=None, stride=1, in_scale_shift=None, slope=0.01, bn=None, packed=None, precision=None):
+    """nn.Conv2d (padding k // 2) of FeatureNet / the compress layer as a HIP kernel (csrc/convnet.hip): implicit GEMM on the matrix cores in the
+    default mode, direct fp32 VALU convolution in fp32 mode.
+    ``in_scale_shift`` [2*cin]: x is the RAW output of a convolution whose InPlaceABN (scale | shift, leaky ``slope``) is applied while x is read.
+    ``bn`` = (gamma, beta, eps, abs_gamma): also reduce the batch statistics of the output and return this layer's own (scale | shift) [2*cout]
+    for the consumer to apply.  ``packed``: conv2d_pack(weight, precision) kept by the caller.  -> (raw output [V,cout,Ho,Wo], scale_shift or None)."""
+    V, cin, Hi, Wi = x.shape
+    cout, cin_w, k, _ = weight.shape
+    if cin_w != cin:
+        raise ValueError(f"conv2d: weight expects {cin_w} input channels, got {cin}")
+    pad = k // 2
+    Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
+    L = _lib.lib()
+    out = torch.empty(V, cout, Ho, Wo, dtype=torch.float32, device=x.device)
+    ss = gamma = beta = ws = None
+    eps, abs_gamma, wsb = 0.0, 0, 0
+    if bn is not None:
+        gamma, beta, eps, abs_gamma = bn
+        ss = torch.empty(2 * cout, dtype=torch.float32, device=x.device)
+        wsb = L.o2345_conv2d_workspace_bytes(V, cout, Ho, Wo)
+        ws = _workspace(wsb, x.device, "conv2d")
+    fn = L.o2345_conv2d_x3 if conv_x3(precision) else L.o2345_conv2d
+    check(fn(_p(x), V, cin, Hi, Wi, _p(in_scale_shift), float(slope), _p(packed if packed is not None else conv2d_pack(weight, precision)),
+             _p(None if bias is None else _f(bias)), cout, k, int(stride), _p(out), _p(None if gamma is None else _f(gamma)),
+             _p(None if beta is None else _f(beta)), float(eps), int(abs_gamma), _p(ss), _p(ws, torch.uint8), wsb, _stream()), "conv2d")
+    return out, ss
+
+
+@_on_device
+def scale_shift_act(x, scale_shift, slope=0.01, want_nchw=True, want_nhwc=False):
+    """leaky_relu(x * scale + shift) of a raw convolution output [V,C,H,W] -> (NCHW or None, channel-last NHWC or None)."""
+    V, C, H, W = x.shape
+    y1 = torch.empty_like(x) if want_nchw else None
+    y2 = torch.empty(V, H, W, C, dtype=torch.float32, device=x.device) if want_nhwc else None
+    check(_lib.lib().o2345_scale_shift_act(_p(x), V, C, H, W, _p(scale_shift), float(slope), _p(y1), _p(y2), _stream()), "scale_shift_act")
+    return y1, y2
+
+
+@_on_device
+def fpn_level(fine, coarse, weight, bias, fine_scale_shift=None, slope=0.01):
+    """FeatureNet._upsample_add(coarse, lateral_1x1(fine)) in one kernel: fine [V,C,H,W] (C = 8 | 16), coarse [V,32,H/2,W/2] -> [V,32,H,W].
+    ``fine_scale_shift``: fine is a raw convolution output, its InPlaceABN is applied on load."""
     V, C, H, W = fine.shape
     if tuple(coarse.shape) != (V, 32, H // 2, W // 2):
         raise ValueError(f"fpn_level: coarse map must be [V,32,H/2,W/2], got {tuple(coarse.shape)} for fine {tuple(fine.shape)}")
     out = torch.empty(V, 32, H, W, dtype=torch.float32, device=fine.device)
-    check(_lib.lib().o2345_fpn_level(_p(fine), C, _p(coarse), _p(weight.reshape(32, C).contiguous()), _p(bias), V, H, W, _p(out), _stream()), "fpn_level")
+    check(_lib.lib().o2345_fpn_level_act(_p(fine), _p(fine_scale_shift), float(slope), C, _p(coarse), _p(_f(weight).reshape(32, C)), _p(_f(bias)), V, H, W,
+                                         _p(out), _stream()), "fpn_level")
     return out
 
 

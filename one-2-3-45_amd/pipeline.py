@@ -67,9 +67,8 @@ def build_volume(wt, imgs, affine_mats, origin, D, voxel_size, fmaps=None):
     V, _, H, W = imgs.shape
     cmaps = None
     if fmaps is None:
-        fmaps, cmaps = fused_pyramid(wt.featurenet, imgs, want_cmaps=True)     # [V,56,H,W] + [V,H,W,64]: MIOpen convs, HIP ABN / FPN / pyramid kernels
-    pre = wt.compress.conv(fmaps).contiguous()                                 # Conv3x3 56->16 (MIOpen)
-    _, feats_nhwc = wt.compress.bn(pre, want_nhwc=True)                        # fused ABN + re-layout (HIP)
+        fmaps, cmaps = fused_pyramid(wt.featurenet, imgs, want_cmaps=True)     # [V,56,H,W] + [V,H,W,64]: HIP convolutions / FPN / pyramid kernels
+    feats_nhwc = wt.compress.forward_nhwc(fmaps)                               # Conv3x3 56->16 + batch stats, then ABN + channel-last re-layout (HIP)
     cnt, row, coords, n = ops.costvol_index(affine_mats, V, H, W, (D, D, D), voxel_size, origin)
     rows = ops.costvol_gather(feats_nhwc, affine_mats, (D, D, D), voxel_size, origin, cnt, coords)
     rows16 = wt.costreg.forward(rows, coords, row, (D, D, D))

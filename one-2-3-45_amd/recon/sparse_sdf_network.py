@@ -127,8 +127,7 @@ class SparseSdfNetwork(nn.Module):
         D = tuple(int(d) for d in self.vol_dims.tolist())
         if sizeH is not None and (int(sizeH) != H or int(sizeW) != W):
             raise NotImplementedError("feature maps must be at image resolution (the fused pyramid is)")
-        pre = self.compress_layer.conv(fm).contiguous()
-        _, feats_nhwc = self.compress_layer.bn(pre, want_nhwc=True)
+        feats_nhwc = self.compress_layer.forward_nhwc(fm)
         aff = proj_mats[0].contiguous().float()
         origin = partial_vol_origin[0]
         if self.lod == 0:

@@ -80,7 +80,43 @@ def scatter_dense(rows, row_of_voxel, dims, want_cf=True):
     return cl, cf, v.float().view(1, 1, dx, dy, dz)
 
 
-def fpn_level(fine, coarse, weight, bias):
+def _ss_act(x, ss, slope):
+    C = x.shape[1]
+    t = x * ss[:C].view(1, -1, 1, 1) + ss[C:].view(1, -1, 1, 1)
+    return torch.where(t >= 0, t, t * slope)
+
+
+def conv_x3(precision=None):
+    return False
+
+
+def conv2d_pack(weight, precision=None):
+    return weight
+
+
+def conv2d(x, weight, bias=None, stride=1, in_scale_shift=None, slope=0.01, bn=None, packed=None, precision=None):
+    """ops.conv2d: raw convolution output + this layer's InPlaceABN (scale | shift) from the batch statistics."""
+    if in_scale_shift is not None:
+        x = _ss_act(x, in_scale_shift, slope)
+    out = F.conv2d(x, weight, bias, stride, weight.shape[-1] // 2)
+    ss = None
+    if bn is not None:
+        gamma, beta, eps, abs_gamma = bn
+        mean, var = out.mean((0, 2, 3)), out.var((0, 2, 3), unbiased=False)
+        g = gamma.abs() + eps if abs_gamma else gamma
+        scale = g / torch.sqrt(var + eps)
+        ss = torch.cat([scale, beta - mean * scale])
+    return out, ss
+
+
+def scale_shift_act(x, scale_shift, slope=0.01, want_nchw=True, want_nhwc=False):
+    y = _ss_act(x, scale_shift, slope)
+    return (y if want_nchw else None), (y.permute(0, 2, 3, 1).contiguous() if want_nhwc else None)
+
+
+def fpn_level(fine, coarse, weight, bias, fine_scale_shift=None, slope=0.01):
+    if fine_scale_shift is not None:
+        fine = _ss_act(fine, fine_scale_shift, slope)
     return F.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True) + F.conv2d(fine, weight.reshape(32, -1, 1, 1), bias)
 
 
@@ -253,7 +289,7 @@ def install(monkeypatch):
     costreg = importlib.import_module("one-2-3-45_amd.costreg")
     featurenet = importlib.import_module("one-2-3-45_amd.featurenet")
     for name in ("costvol_index", "costvol_gather", "visible_count_list", "costvol_gather_list", "build_index_grid", "scatter_dense", "sdf_mlp",
-                 "pack_color_maps", "color_points", "render_rays", "marching_cubes", "prune_dilate", "sparse_downsample", "sparse_conv3d", "bn_act_rows", "fpn_level", "pyramid_pack"):
+                 "pack_color_maps", "color_points", "render_rays", "marching_cubes", "prune_dilate", "sparse_downsample", "sparse_conv3d", "bn_act_rows", "fpn_level", "pyramid_pack", "conv2d", "conv2d_pack", "conv_x3", "scale_shift_act"):
         monkeypatch.setattr(ops, name, globals()[name])
     spnn = importlib.import_module("one-2-3-45_amd.shims.torchsparse.nn")
     monkeypatch.setattr(spnn, "_require_device", lambda t: None)

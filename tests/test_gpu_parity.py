@@ -142,6 +142,56 @@ def test_bn_and_abn(dev, ops):
         close(y2, ref.permute(0, 2, 3, 1), what=f"abn nhwc C={C}")
 
 
+CONV_SHAPES = [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1), (16, 32, 5, 2), (32, 32, 3, 1), (32, 32, 1, 1), (32, 16, 3, 1), (32, 8, 3, 1),
+               (56, 16, 3, 1)]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride", CONV_SHAPES)
+@pytest.mark.parametrize("hw", [(40, 36), (21, 67)])
+@pytest.mark.parametrize("prec", ["f16x3", "fp32"])
+def test_conv2d_vs_torch(dev, ops, cin, cout, k, stride, hw, prec):
+    """csrc/convnet.hip (every FeatureNet / compress-layer shape; ragged tiles, odd sizes; matrix-core form and strict fp32 VALU form) against
+    ATen's fp32 conv2d on the CPU: plain convolution with bias, then the fused form -- producer ABN applied on load, batch statistics of the
+    output reduced into this layer's (scale | shift)."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(cin * 100 + cout + k)
+    V = 3
+    x = torch.from_numpy(rng.normal(0.2, 1.0, (V, cin) + hw).astype(np.float32))
+    w = torch.from_numpy((rng.normal(0, 1.0, (cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(0, 0.3, cout).astype(np.float32))
+    y, ss = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), stride, precision=prec)
+    assert ss is None
+    ref = F.conv2d(x, w, b, stride, k // 2)
+    assert y.shape == ref.shape
+    close(y, ref, rel=1e-5, what="conv2d + bias")
+    # fused form
+    in_ss = torch.from_numpy(np.concatenate([rng.uniform(-1.5, 1.5, cin), rng.normal(0, 0.3, cin)]).astype(np.float32))
+    gamma = torch.from_numpy(rng.uniform(-1.5, 1.5, cout).astype(np.float32)); beta = torch.from_numpy(rng.normal(0, 0.2, cout).astype(np.float32))
+    y, ss = ops.conv2d(x.to(dev), w.to(dev), None, stride, in_ss.to(dev), 0.01, bn=(gamma.to(dev), beta.to(dev), 1e-5, True), precision=prec)
+    t = x * in_ss[:cin].view(1, -1, 1, 1) + in_ss[cin:].view(1, -1, 1, 1)
+    xa = torch.where(t >= 0, t, t * 0.01)
+    ref = F.conv2d(xa, w, None, stride, k // 2)
+    close(y, ref, rel=1e-5, what="conv2d of the activated input")
+    rd = ref.double()
+    mean, var = rd.mean((0, 2, 3)), rd.var((0, 2, 3), unbiased=False)
+    scale = (gamma.double().abs() + 1e-5) / torch.sqrt(var + 1e-5)
+    close(ss[:cout], scale.float(), rel=2e-5, what="ABN scale from the fused statistics")
+    close(ss[cout:], (beta.double() - mean * scale).float(), rel=2e-5, what="ABN shift from the fused statistics")
+    if cout in (8, 16, 32):
+        y1, y2 = ops.scale_shift_act(y, ss, 0.01, want_nchw=True, want_nhwc=True)
+        close(y1, O.abn_train(ref, gamma, beta), rel=2e-5, what="conv + ABN")
+        assert torch.equal(y2, y1.permute(0, 2, 3, 1))
+
+
+def test_conv2d_rejects_other_shapes(dev, ops):
+    with pytest.raises(Exception, match="no kernel for"):
+        ops.conv2d(torch.zeros(1, 4, 8, 8, device=dev), torch.zeros(8, 4, 3, 3, device=dev), precision="fp32")
+    with pytest.raises(Exception, match="no kernel for"):
+        ops.conv2d(torch.zeros(1, 16, 8, 8, device=dev), torch.zeros(8, 16, 7, 7, device=dev), precision="f16x3")
+    with pytest.raises(ValueError, match="CUDA"):
+        ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(8, 3, 3, 3))
+
+
 def _pts(n, seed=0):
     rng = np.random.default_rng(seed)
     p = rng.uniform(-1.1, 1.1, (n, 3)).astype(np.float32)

@@ -1,42 +1,45 @@
-"""Layer-by-layer steady-state timing of FeatureNet + pyramid + compress layer (diagnostic)."""
+"""Steady-state timing of FeatureNet + pyramid + compress layer on the HIP convolution engine (diagnostic): per layer and whole."""
 import os, sys
-import numpy as np, torch, torch.nn.functional as F
+import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.argv = [sys.argv[0]]
 import bench
-pipeline = bench.pipeline
+pipeline, ops = bench.pipeline, bench.ops
+fn = __import__("importlib").import_module("one-2-3-45_amd.featurenet")
 dev = torch.device("cuda:0")
 wt = pipeline.SceneWeights(dev, seed=0)
 inp = bench.make_inputs(dev, 8, 0, 2)
-x = inp["imgs"]
+x = inp["imgs"].contiguous().float()
 net = wt.featurenet
-def timed(fn_, reps=5):
-    fn_(); fn_(); torch.cuda.synchronize(); ts = []
+
+
+def timed(f, reps=7):
+    f(); f(); torch.cuda.synchronize(); ts = []
     for _ in range(reps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); a.record(); r = fn_(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
-    return min(ts), r
-tot = 0.0
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); a.record(); r = f(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    return min(ts) * 1e3, r
+
+
 with torch.no_grad():
-    cur = x
-    outs = {}
+    r, ss = x, None
+    raws = []
     for name, seq in (("conv0", net.conv0), ("conv1", net.conv1), ("conv2", net.conv2)):
         for i, blk in enumerate(seq):
-            tc, y = timed(lambda: blk.conv(cur))
-            tb, y2 = timed(lambda: blk.bn(y))
-            print(f"{name}.{i}  conv {tuple(blk.conv.weight.shape)} s{blk.conv.stride[0]}: {tc*1e3:7.1f} us   abn: {tb*1e3:6.1f} us   out {tuple(y2.shape)}")
-            tot += tc + tb
-            cur = y2
-        outs[name] = cur
-    for nm, m, src in (("toplayer", net.toplayer, outs["conv2"]), ("lat1", net.lat1, outs["conv1"]), ("lat0", net.lat0, outs["conv0"])):
-        t, _ = timed(lambda: m(src)); print(f"{nm}: {t*1e3:7.1f} us"); tot += t
-    f2 = net.toplayer(outs["conv2"])
-    t, f1 = timed(lambda: net._up_add(f2, net.lat1(outs["conv1"]))); print(f"up_add1 (incl lat1): {t*1e3:7.1f} us")
-    t, f0 = timed(lambda: net._up_add(f1, net.lat0(outs["conv0"]))); print(f"up_add0 (incl lat0): {t*1e3:7.1f} us")
-    t, s1 = timed(lambda: net.smooth1(f1)); print(f"smooth1: {t*1e3:7.1f} us"); tot += t
-    t, s0 = timed(lambda: net.smooth0(f0)); print(f"smooth0: {t*1e3:7.1f} us"); tot += t
-    t, fm = timed(lambda: torch.cat([F.interpolate(f2, scale_factor=4, mode="bilinear", align_corners=True), F.interpolate(s1, scale_factor=2, mode="bilinear", align_corners=True), s0], dim=1))
-    print(f"pyramid fuse (2 interpolate + cat): {t*1e3:7.1f} us")
-    t, _ = timed(lambda: pipeline.ops.pack_color_maps(fm.contiguous(), x.contiguous())); print(f"pack_color_maps: {t*1e3:7.1f} us")
-    t, pre = timed(lambda: wt.compress.conv(fm)); print(f"compress conv: {t*1e3:7.1f} us")
-    t, _ = timed(lambda: wt.compress.bn(pre.contiguous(), want_nhwc=True)); print(f"compress abn: {t*1e3:7.1f} us")
-    t, _ = timed(lambda: pipeline.featurenet_forward(wt, x) if hasattr(pipeline, "featurenet_forward") else __import__("importlib").import_module("one-2-3-45_amd.featurenet").fused_pyramid(net, x)); print(f"featurenet + pyramid total: {t*1e3:7.1f} us")
+            t, (r2, ss2) = timed(lambda: blk.raw(r, ss))
+            w = blk.conv.weight
+            flop = 2 * r2.numel() * w.shape[1] * w.shape[2] * w.shape[3]
+            print(f"{name}.{i} {tuple(w.shape)} s{blk.conv.stride[0]} -> {tuple(r2.shape)}: {t:7.1f} us  ({flop / t / 1e6:6.1f} TFLOP/s)")
+            r, ss = r2, ss2
+        raws.append((r, ss))
+    (c0, ss0), (c1, ss1), (c2, ss2_) = raws
+    t, (f2, _) = timed(lambda: ops.conv2d(c2, net.toplayer.weight.detach(), net.toplayer.bias.detach(), 1, ss2_, 0.01, packed=fn.packed_weight(net.toplayer))); print(f"toplayer: {t:7.1f} us")
+    t, f1 = timed(lambda: ops.fpn_level(c1, f2, net.lat1.weight.detach(), net.lat1.bias.detach(), ss1, 0.01)); print(f"fpn level 1: {t:7.1f} us")
+    t, f0 = timed(lambda: ops.fpn_level(c0, f1, net.lat0.weight.detach(), net.lat0.bias.detach(), ss0, 0.01)); print(f"fpn level 0: {t:7.1f} us")
+    t, (s1, _) = timed(lambda: ops.conv2d(f1, net.smooth1.weight.detach(), net.smooth1.bias.detach(), packed=fn.packed_weight(net.smooth1))); print(f"smooth1: {t:7.1f} us")
+    t, (s0, _) = timed(lambda: ops.conv2d(f0, net.smooth0.weight.detach(), net.smooth0.bias.detach(), packed=fn.packed_weight(net.smooth0))); print(f"smooth0: {t:7.1f} us")
+    t, (fm, cm) = timed(lambda: ops.pyramid_pack(f2, s1, s0, x)); print(f"pyramid_pack: {t:7.1f} us")
+    t, (pre, ssc) = timed(lambda: wt.compress.raw(fm)); print(f"compress conv 56->16: {t:7.1f} us  ({2 * pre.numel() * 56 * 9 / t / 1e6:6.1f} TFLOP/s)")
+    t, _ = timed(lambda: ops.scale_shift_act(pre, ssc, 0.01, want_nchw=False, want_nhwc=True)); print(f"compress ABN apply + NHWC: {t:7.1f} us")
+    t, _ = timed(lambda: fn.fused_pyramid(net, x, want_cmaps=True)); print(f"featurenet + pyramid total: {t:7.1f} us")
+    t, _ = timed(lambda: wt.compress.forward_nhwc(fm)); print(f"compress layer total: {t:7.1f} us")
+    t, _ = timed(lambda: pipeline.build_volume(wt, inp["imgs"], inp["aff"], inp["origin"], 128, 2.0 / 127)); print(f"build_volume total: {t:7.1f} us")

@@ -21,8 +21,7 @@ def timed(fn_, reps=5):
 imgs, aff, origin = inp["imgs"], inp["aff"], inp["origin"]
 with torch.no_grad():
     t, fmaps = timed(lambda: fn.fused_pyramid(wt.featurenet, imgs).contiguous()); print(f"featurenet + pyramid  {t:.3f} ms")
-    t, pre = timed(lambda: wt.compress.conv(fmaps).contiguous()); print(f"compress conv         {t:.3f} ms")
-    t, (_, feats) = timed(lambda: wt.compress.bn(pre, want_nhwc=True)); print(f"compress ABN (HIP)    {t:.3f} ms")
+    t, feats = timed(lambda: wt.compress.forward_nhwc(fmaps)); print(f"compress conv + ABN   {t:.3f} ms")
     t, (cnt, row, coords, n) = timed(lambda: ops.costvol_index(aff, V, 256, 256, (D, D, D), vs, origin)); print(f"costvol index         {t:.3f} ms  ({int(n)} voxels)")
     t, rows = timed(lambda: ops.costvol_gather(feats, aff, (D, D, D), vs, origin, cnt, coords)); print(f"costvol gather        {t:.3f} ms")
     t, rows16 = timed(lambda: wt.costreg.forward(rows, coords, row, (D, D, D))); print(f"sparse CNN            {t:.3f} ms")
