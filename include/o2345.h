@@ -207,6 +207,9 @@ int o2345_pack_color_maps(const float* feat_nchw, const float* color_nchw, int V
                           void* stream);
 int o2345_view_count(const float* pts, long long n, const float* maskvol, int D, const float* proj, int V, int H, int W,
                      uint8_t* out, void* stream);
+/* the same count only where skip_if_positive[i] <= 0 (NULL: everywhere): the colour kernels write out_nviews for the points they evaluate */
+int o2345_view_count_unlisted(const float* pts, long long n, const float* skip_if_positive, const float* maskvol, int D, const float* proj,
+                              int V, int H, int W, uint8_t* out, void* stream);
 int o2345_color_points(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
                        const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
                        const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,

@@ -126,8 +126,8 @@ __device__ __forceinline__ bool geo_valid(const float* __restrict__ maskvol, int
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const float w = ax.w[a] * ay.w[b] * az.w[c];
-                if (w != 0.f) m += w * maskvol[((size_t)ax.i[a] * D + ay.i[b]) * D + az.i[c]];
+                // all eight taps are requested together (indices are clamped, a zero weight adds an exact zero): no branch per tap
+                m += ax.w[a] * ay.w[b] * az.w[c] * maskvol[((size_t)ax.i[a] * D + ay.i[b]) * D + az.i[c]];
             }
     return m > 0.f;
 }
@@ -347,9 +347,10 @@ __global__ __launch_bounds__(256) void k_color_points(ColorArgs a, const float* 
 // cheap -- feeds the per-ray colour mask (rendering_network.py:124-128)
 __global__ __launch_bounds__(256) void k_view_count(const float* __restrict__ pts, long long n, const float* __restrict__ maskvol,
                                                     int D, const float* __restrict__ proj, int V, int H, int W,
-                                                    uint8_t* __restrict__ out) {
+                                                    uint8_t* __restrict__ out, const float* __restrict__ skip /*or null*/) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (skip && skip[i] > 0.f) return;                       // the colour kernel that evaluates this point writes the same count (out_nviews)
     const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
     int c = 0;
     if (geo_valid(maskvol, D, x, y, z)) {
@@ -398,12 +399,17 @@ int o2345_pack_color_maps(const float* feat_nchw, const float* color_nchw, int V
     return check_launch("pack_color_maps");
 }
 
-int o2345_view_count(const float* pts, long long n, const float* maskvol, int D, const float* proj, int V, int H, int W,
-                     uint8_t* out, void* stream) {
+int o2345_view_count_unlisted(const float* pts, long long n, const float* skip_if_positive, const float* maskvol, int D, const float* proj, int V,
+                              int H, int W, uint8_t* out, void* stream) {
     O2345_REQUIRE(pts && maskvol && proj && out, "view_count: null pointer");
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_view_count, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, n, maskvol, D, proj, V, H, W, out);
+    hipLaunchKernelGGL(k_view_count, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, n, maskvol, D, proj, V, H, W, out, skip_if_positive);
     return check_launch("view_count");
+}
+
+int o2345_view_count(const float* pts, long long n, const float* maskvol, int D, const float* proj, int V, int H, int W,
+                     uint8_t* out, void* stream) {
+    return o2345_view_count_unlisted(pts, n, nullptr, maskvol, D, proj, V, H, W, out, stream);
 }
 
 int o2345_color_points(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,

@@ -166,8 +166,8 @@ int o2345_color_points_mfma(const float* blob, const float* vol_cl, const float*
                             const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
                             const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
                             const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
-int o2345_view_count(const float* pts, long long n, const float* maskvol, int D, const float* proj, int V, int H, int W,
-                     uint8_t* out, void* stream);
+int o2345_view_count_unlisted(const float* pts, long long n, const float* skip_if_positive, const float* maskvol, int D, const float* proj, int V,
+                              int H, int W, uint8_t* out, void* stream);
 
 // ---- stage entry points (used by the parity tests; the orchestrator below calls the same kernels) -----------------
 int o2345_ray_coarse_jitter(const float* rays_o, const float* rays_d, int R, float near, float far, int S, const float* t_rand,
@@ -291,13 +291,15 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     if ((rc = o2345_ray_finalize(io->rays_o, io->rays_d, R, z, (int)S, sample_dist, io->maskvol, io->D, io->mid_z, io->dists, fpts, io->pm, io->sdf, io->grad, io->rgb, list, count, stream))) return rc;
     hipLaunchKernelGGL(k_quirk_first100, dim3(1), dim3(128), 0, s, count, list, R, (int)S);
     if ((rc = sdf_eval(2, fpts, list, count, 0, io->sdf, io->grad))) return rc;
-    if ((rc = o2345_view_count(fpts, (long long)S * R, io->maskvol, io->D, io->proj, io->V, io->H, io->W, io->nviews, stream))) return rc;
+    // valid-view counts (feed the per-ray colour mask): the colour kernels write them for the points they evaluate (the occupied ones, 88 % at
+    // BASELINE config 2); this pass covers the rest (four IEEE divisions per view make it VALU-bound: 0.48 ms over all points)
+    if ((rc = o2345_view_count_unlisted(fpts, (long long)S * R, io->pm, io->maskvol, io->D, io->proj, io->V, io->H, io->W, io->nviews, stream))) return rc;
     if (io->color_x3_blob)
-        rc = o2345_color_points_x3(io->color_x3_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, nullptr, stream);
+        rc = o2345_color_points_x3(io->color_x3_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, io->nviews, stream);
     else if (io->color_mfma_blob)
-        rc = o2345_color_points_mfma(io->color_mfma_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, nullptr, stream);
+        rc = o2345_color_points_mfma(io->color_mfma_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, io->nviews, stream);
     else
-        rc = o2345_color_points(io->color_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, nullptr, stream);
+        rc = o2345_color_points(io->color_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, io->nviews, stream);
     if (rc) return rc;
     if ((rc = o2345_ray_composite(io->rays_o, io->rays_d, R, (int)S, io->mid_z, io->dists, io->pm, io->sdf, io->grad, io->rgb, io->nviews, io->inv_s, io->alpha_inter_ratio, io->background,
                                   io->color, io->depth, io->weights, io->cdf, io->weights_sum, io->weights_max, io->depth_var, io->alpha_sum, io->grad_err, io->color_mask, stream))) return rc;

@@ -187,21 +187,22 @@ __global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ x
     }
 }
 
+// one block per channel: thread t sums every 256-th partial in index order, then a fixed tree over the 256 sub-sums (wave shuffles, 4 wave
+// totals in LDS): deterministic, and ~4 us instead of the 13-19 us of a single block walking all partials of all channels
 template <int C>
 __global__ __launch_bounds__(256) void k_col_finish(const double* __restrict__ part, int nblocks, int n, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float eps, int abs_gamma,
                                                     float* __restrict__ scale_shift /*[2,C]*/, float* __restrict__ mean_var /*[2,C] or null*/) {
-    // 256/C threads per channel, each sums every (256/C)-th partial in index order, then thread 0 of the channel adds the
-    // 256/C sub-sums in index order: a fixed summation tree (deterministic), 64x shorter dependent chain than one thread per channel
-    constexpr int J = 256 / C;
-    __shared__ double sm[J][2][C];
-    const int c = threadIdx.x % C, j = threadIdx.x / C;
+    __shared__ double sm[2][4];
+    const int c = blockIdx.x;
     double s = 0.0, s2 = 0.0;
-    for (int b = j; b < nblocks; b += J) { s += part[((size_t)b * 2 + 0) * C + c]; s2 += part[((size_t)b * 2 + 1) * C + c]; }
-    sm[j][0][c] = s; sm[j][1][c] = s2;
+    for (int b = threadIdx.x; b < nblocks; b += 256) { s += part[((size_t)b * 2 + 0) * C + c]; s2 += part[((size_t)b * 2 + 1) * C + c]; }
+    for (int off = 32; off; off >>= 1) { s += __shfl_xor(s, off); s2 += __shfl_xor(s2, off); }
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = s; sm[1][threadIdx.x >> 6] = s2; }
     __syncthreads();
-    if (j != 0) return;
-    for (int i = 1; i < J; ++i) { s += sm[i][0][c]; s2 += sm[i][1][c]; }
+    if (threadIdx.x != 0) return;
+    s = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
+    s2 = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
     const double mean = s / n;
     double var = s2 / n - mean * mean;          // biased batch variance
     if (var < 0.0) var = 0.0;
@@ -384,7 +385,7 @@ int o2345_bn_act_rows(const float* x, int n, int C, const float* gamma, const fl
 #define O2345_BN_CASE(CC)                                                                                             \
     if (C == CC) {                                                                                                    \
         hipLaunchKernelGGL(k_col_partial<CC>, dim3(nb), dim3(256), 0, s, x, n, part);                                 \
-        hipLaunchKernelGGL(k_col_finish<CC>, dim3(1), dim3(256), 0, s, part, nb, n, gamma, beta, eps, abs_gamma, ss, mean_var_out); \
+        hipLaunchKernelGGL(k_col_finish<CC>, dim3(CC), dim3(256), 0, s, part, nb, n, gamma, beta, eps, abs_gamma, ss, mean_var_out); \
         hipLaunchKernelGGL(k_bn_act<CC>, dim3(cdiv(ne, 1024)), dim3(256), 0, s, x, ne, ss, slope, skip, y);          \
     }
     O2345_BN_CASE(16) O2345_BN_CASE(32) O2345_BN_CASE(64)
