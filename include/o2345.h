@@ -228,6 +228,12 @@ int o2345_color_points_x3(const float* blob, const float* vol_cl, const float* m
                           const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
                           const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
                           const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
+/* GeneralRenderingNetwork.forward on MATERIALISED inputs in the reference's own (view-major) layout (models/rendering_network.py:75-129):
+ * geometry_feat [P,16], rgb_feat [V,P,59] (colours | features), ray_diff [V,P,4], mask [V,P] (non-zero = valid) -> rgb [P,3] and the number of
+ * valid views [P] (optional).  blob: the x3 (x3 = 1) or fp32-MFMA (x3 = 0) packing of the network.  The fused Projector path above is the fast
+ * one; this entry makes the network a drop-in on its own (any Projector). */
+int o2345_color_from_features(const float* blob, int x3, const float* geometry_feat, const float* rgb_feat, const float* ray_diff,
+                              const float* mask, int V, long long P, float* out_rgb, uint8_t* out_nviews, void* stream);
 
 /* ---- marching cubes (replaces mcubes.marching_cubes, call site models/sparse_neus_renderer.py:932) -----------------
  * u [n0,n1,n2] float32 on the device; iso is a DOUBLE like PyMCubes' isovalue (ABI 1.2).  count() synchronises the stream and returns the sizes on the host;

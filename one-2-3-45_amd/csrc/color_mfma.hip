@@ -343,6 +343,17 @@ int o2345_color_points_mfma(const float* blob, const float* vol_cl, const float*
     return color_mfma_launch(false, blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews, stream);
 }
 
+// GeneralRenderingNetwork.forward(geometry_feat, rgb_feat, ray_diff, mask) on materialised tensors in the reference's layout (view-major):
+// geometry_feat [P,16], rgb_feat [V,P,59], ray_diff [V,P,4], mask [V,P] (non-zero = valid) -> rgb [P,3], number of valid views [P].
+// x3 = 1: blob from weights.pack_color_x3_blob (split-f16 form), 0: weights.pack_color_mfma_blob (fp32 MFMA).
+int o2345_color_from_features(const float* blob, int x3, const float* geometry_feat, const float* rgb_feat, const float* ray_diff, const float* mask,
+                              int V, long long P, float* out_rgb, uint8_t* out_nviews, void* stream) {
+    O2345_REQUIRE(blob && geometry_feat && rgb_feat && ray_diff && mask && out_rgb, "color_from_features: null pointer");
+    O2345_REQUIRE(V >= 1 && P >= 0, "color_from_features: bad sizes");
+    if (P == 0) return 0;
+    return color_feats_launch(x3, blob, geometry_feat, rgb_feat, ray_diff, mask, V, P, out_rgb, out_nviews, stream);
+}
+
 // split-f16 form (blob from weights.pack_color_x3_blob, o2345_color_x3_blob_floats() floats)
 int o2345_color_points_x3(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
                           const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,

@@ -58,6 +58,11 @@ struct ColorMArgs {
     const float* pts; const int* index; const int* n_dev; long long n;
     const float* query_cam; const float* normals;
     float* out_rgb; uint8_t* out_nviews;
+    // materialised inputs of GeneralRenderingNetwork.forward (k_color_pts<.., FEATS = true> only): the reference's view-major tensors
+    const float* f_geo;       // [P,16]
+    const float* f_rgb;       // [V,P,59]  colours (3) | features (56)
+    const float* f_rdiff;     // [V,P,4]
+    const float* f_mask;      // [V,P]     non-zero = the projection is valid
 };
 
 // ELU is evaluated ~150 times per lane and tile (a quarter of the kernel's VALU instructions), so the whole network runs in a
@@ -206,6 +211,8 @@ __device__ __forceinline__ void cm_project(const float* __restrict__ P, float x,
 
 
 // csrc/color_pts.hip: the points-as-columns kernel (default); O2345_COLOR_KERNEL=tiles selects k_color_mfma (csrc/color_mfma.hip)
+int color_feats_launch(int x3, const float* blob, const float* geo, const float* rgb_feat, const float* ray_diff, const float* mask, int V, long long n,
+                       float* out_rgb, uint8_t* out_nviews, void* stream);
 int color_pts_launch(int x3, const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps, const float* proj,
                      const float* cam_pos, int V, int H, int W, const float* pts, const int32_t* index, const int32_t* n_dev, long long n,
                      const float* query_cam, const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);

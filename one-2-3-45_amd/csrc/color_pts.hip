@@ -69,6 +69,23 @@ __device__ __forceinline__ void gather_now(const ColorMArgs& a, int h, int v, co
         }
 }
 
+// FEATS form (GeneralRenderingNetwork.forward on materialised tensors, rendering_network.py:75-129): the same per-view quantities read from the
+// reference's view-major inputs instead of being derived from the point
+__device__ __forceinline__ ViewGeom feat_geom(const ColorMArgs& a, int v, long long slot, float s_abs) {
+    ViewGeom g;
+    const float4 rd = *reinterpret_cast<const float4*>(a.f_rdiff + ((size_t)v * a.n + slot) * 4);
+    g.rd[0] = rd.x; g.rd[1] = rd.y; g.rd[2] = rd.z; g.rd[3] = rd.w;
+    g.e = __builtin_amdgcn_exp2f(s_abs * (rd.w - 1.f));
+    g.m = a.f_mask[(size_t)v * a.n + slot] != 0.f ? 1.f : 0.f;
+    g.gx = g.gy = 0.f;
+    return g;
+}
+__device__ __forceinline__ void load_feats(const ColorMArgs& a, int h, int v, long long slot, float (&rf)[32]) {
+    const float* src = a.f_rgb + ((size_t)v * a.n + slot) * 59 + 32 * h;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) rf[c] = (h == 0 || c < 27) ? src[(h == 0 || c < 27) ? c : 0] * LOG2E : 0.f;
+}
+
 // ray_dir_fc (4 -> 16 -> 59) of view geometry g in two steps: layer 1 -> d16, layer 2 added to this half's 32 gathered pixel floats
 template <bool X3>
 __device__ __forceinline__ void direction_layer1(const float* lds, int tail, int lane, int h, const ViewGeom& g, float m1, float (&d16)[8]) {
@@ -92,7 +109,7 @@ __device__ __forceinline__ void direction_layer2(const float* lds, int tail, int
 
 // 512-thread workgroups (2 waves per SIMD, <= 256 VGPRs: no spills; measured 45.2 ms vs 46.0 ms with 768 threads / 168 VGPRs / 140 B of spills)
 constexpr int CP_THREADS = 512;
-template <bool X3>
+template <bool X3, bool FEATS>
 __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // staged: [A segments | biases and per-lane vectors] [scalars (4)] [A_S]  -- the VALU weight rows W_S of color_mfma.hip are skipped
@@ -117,11 +134,17 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
         const long long i = tile * 32 + j;
         const bool live = i < n;
         const long long slot = live ? (a.index ? (long long)a.index[i] : i) : 0;
-        const float px = live ? a.pts[3 * slot] : 0.f, py = live ? a.pts[3 * slot + 1] : 0.f, pz = live ? a.pts[3 * slot + 2] : 0.f;
+        const float px = (live && !FEATS) ? a.pts[3 * slot] : 0.f, py = (live && !FEATS) ? a.pts[3 * slot + 1] : 0.f,
+                    pz = (live && !FEATS) ? a.pts[3 * slot + 2] : 0.f;
         // ---- pass 0: geometry feature (this half's 8 channels), validity, query direction ---------------------------------------
         float bs[72];                               // per-half operands of the shared rows: geo (8) | mean (32) | var (32)
         bool gvalid;
-        {
+        if constexpr (FEATS) {
+            const float4* g4 = reinterpret_cast<const float4*>(a.f_geo + (size_t)slot * 16) + 2 * h;
+            const float4 t0 = g4[0], t1 = g4[1];
+            bs[0] = t0.x; bs[1] = t0.y; bs[2] = t0.z; bs[3] = t0.w; bs[4] = t1.x; bs[5] = t1.y; bs[6] = t1.z; bs[7] = t1.w;
+            gvalid = true;
+        } else {
 #pragma unroll
             for (int c = 0; c < 8; ++c) bs[c] = 0.f;
             float msum = 0.f;
@@ -144,8 +167,9 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
             }
             gvalid = fabsf(px) < 1.f && fabsf(py) < 1.f && fabsf(pz) < 1.f && msum > 0.f;
         }
-        float qx, qy, qz;
-        if (a.normals) {
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if constexpr (FEATS) {
+        } else if (a.normals) {
             const float nx = a.normals[3 * slot], ny = a.normals[3 * slot + 1], nz = a.normals[3 * slot + 2];
             const float rn = crcp(fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-6f));
             qx = nx * rn; qy = ny * rn; qz = nz * rn;
@@ -157,6 +181,10 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
         // min over ALL views of the pooling exponent (rendering_network.py:94: exp(...).min over the view axis, mask or not)
         float emin = INFINITY;
         for (int v = 0; v < V; ++v) {
+            if constexpr (FEATS) {
+                emin = fminf(emin, __builtin_amdgcn_exp2f(s_abs * (a.f_rdiff[((size_t)v * a.n + slot) * 4 + 3] - 1.f)));
+                continue;
+            }
             const float sx = a.cam_pos[3 * v] - px, sy = a.cam_pos[3 * v + 1] - py, sz = a.cam_pos[3 * v + 2] - pz;
             const float rsn = crcp(sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f);
             const float dot = qx * (sx * rsn) + qy * (sy * rsn) + qz * (sz * rsn);
@@ -171,9 +199,10 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
             for (int c = 0; c < 32; ++c) { mean[c] = 0.f; m2[c] = 0.f; }
 #pragma unroll 1
             for (int v = 0; v < V; ++v) {
-                const ViewGeom g = view_geom(a, v, px, py, pz, qx, qy, qz, gvalid, s_abs);
+                const ViewGeom g = FEATS ? feat_geom(a, v, slot, s_abs) : view_geom(a, v, px, py, pz, qx, qy, qz, gvalid, s_abs);
                 float rf[32];
-                gather_now(a, h, v, g, rf);
+                if constexpr (FEATS) load_feats(a, h, v, slot, rf);
+                else gather_now(a, h, v, g, rf);
                 {
                     float d16[8];
                     direction_layer1<X3>(lds, TAIL, lane, h, g, m1, d16);
@@ -212,10 +241,11 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
         float smax = -INFINITY, ssum = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
-            const ViewGeom g = view_geom(a, v, px, py, pz, qx, qy, qz, gvalid, s_abs);
+            const ViewGeom g = FEATS ? feat_geom(a, v, slot, s_abs) : view_geom(a, v, px, py, pz, qx, qy, qz, gvalid, s_abs);
             const float m = g.m;
             float rf[32];
-            gather_now(a, h, v, g, rf);
+            if constexpr (FEATS) load_feats(a, h, v, slot, rf);
+            else gather_now(a, h, v, g, rf);
             const float rgb0 = rf[0], rgb1 = rf[1], rgb2 = rf[2];   // log2(e) * colours (meaningful in half 0), before the direction feature
             {
                 float d16[8];
@@ -333,13 +363,34 @@ int color_pts_launch(int x3, const float* blob, const float* vol_cl, const float
     const size_t lds = (size_t)(x3 ? (CX_A_END + CM_W_S - CM_BIAS0) + 4 + 2 * 9 * 512 : CM_W_S + 4 + 2 * 72 * 64) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (x3) {
-        O2345_HIP(hipFuncSetAttribute((const void*)k_color_pts<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_color_pts<true>), dim3(grid), dim3(threads), lds, s, a);
+        O2345_HIP(hipFuncSetAttribute((const void*)k_color_pts<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_color_pts<true, false>), dim3(grid), dim3(threads), lds, s, a);
     } else {
-        O2345_HIP(hipFuncSetAttribute((const void*)k_color_pts<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_color_pts<false>), dim3(grid), dim3(threads), lds, s, a);
+        O2345_HIP(hipFuncSetAttribute((const void*)k_color_pts<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_color_pts<false, false>), dim3(grid), dim3(threads), lds, s, a);
     }
     return check_launch("color_points (points-as-columns kernel)");
+}
+
+// GeneralRenderingNetwork.forward on the reference's materialised tensors (the drop-in form; the fused Projector path above is the fast one)
+int color_feats_launch(int x3, const float* blob, const float* geo, const float* rgb_feat, const float* ray_diff, const float* mask, int V, long long n,
+                       float* out_rgb, uint8_t* out_nviews, void* stream) {
+    ColorMArgs a{};
+    a.blob = blob; a.V = V; a.n = n; a.out_rgb = out_rgb; a.out_nviews = out_nviews;
+    a.f_geo = geo; a.f_rgb = rgb_feat; a.f_rdiff = ray_diff; a.f_mask = mask;
+    const int n_cu = cu_count();
+    const long long per_block = (long long)(CP_THREADS / 64) * 32;
+    const unsigned grid = persistent_grid((n + per_block - 1) / per_block, n_cu);
+    const size_t lds = (size_t)(x3 ? (CX_A_END + CM_W_S - CM_BIAS0) + 4 + 2 * 9 * 512 : CM_W_S + 4 + 2 * 72 * 64) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (x3) {
+        O2345_HIP(hipFuncSetAttribute((const void*)k_color_pts<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_color_pts<true, true>), dim3(grid), dim3(CP_THREADS), lds, s, a);
+    } else {
+        O2345_HIP(hipFuncSetAttribute((const void*)k_color_pts<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_color_pts<false, true>), dim3(grid), dim3(CP_THREADS), lds, s, a);
+    }
+    return check_launch("color_from_features");
 }
 
 }  // namespace o2345

@@ -412,6 +412,22 @@ def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=Non
 
 
 @_on_device
+def color_from_features(blob, geometry_feat, rgb_feat, ray_diff, mask, x3=True, want_nviews=True):
+    """GeneralRenderingNetwork.forward on materialised tensors in the reference's layout: geometry_feat [P,16], rgb_feat [V,P,59],
+    ray_diff [V,P,4], mask [V,P] -> (rgb [P,3], valid views uint8 [P]).  blob: pack_color_x3_blob (x3) or pack_color_mfma_blob."""
+    V, P, C = rgb_feat.shape
+    if C != 59 or tuple(geometry_feat.shape) != (P, 16) or tuple(ray_diff.shape) != (V, P, 4) or tuple(mask.shape) != (V, P):
+        raise ValueError(f"color_from_features: expected geometry_feat [P,16], rgb_feat [V,P,59], ray_diff [V,P,4], mask [V,P]; got "
+                         f"{tuple(geometry_feat.shape)}, {tuple(rgb_feat.shape)}, {tuple(ray_diff.shape)}, {tuple(mask.shape)}")
+    rgb = torch.empty(P, 3, dtype=torch.float32, device=rgb_feat.device)
+    nv = torch.empty(P, dtype=torch.uint8, device=rgb_feat.device) if want_nviews else None
+    if P:
+        check(_lib.lib().o2345_color_from_features(_p(blob), int(bool(x3)), _p(_f(geometry_feat)), _p(_f(rgb_feat)), _p(_f(ray_diff)), _p(_f(mask)), V, P,
+                                                   _p(rgb), _p(nv, torch.uint8), _stream()), "color_from_features")
+    return rgb, nv
+
+
+@_on_device
 def view_count(pts, maskvol, D, proj, V, H, W):
     out = torch.empty(pts.shape[0], dtype=torch.uint8, device=pts.device)
     check(_lib.lib().o2345_view_count(_p(pts), pts.shape[0], _p(maskvol), D, _p(proj), V, H, W, _p(out, torch.uint8), _stream()), "view_count")

@@ -76,5 +76,14 @@ class GeneralRenderingNetwork(nn.Module):
             R, S = d.shape
             valid = ((nv.view(R, S) >= 2).float().sum(1) > 8)
             return rgb.view(R, S, 3), valid
-        raise NotImplementedError("o2345 GeneralRenderingNetwork.forward expects the DeferredColour handle produced by "
-                                  "o2345's Projector (materialised [R,S,V,193] inputs are what this back end removes)")
+        # the reference's own call form (rendering_network.py:75-83): geometry_feat [R,S,16], rgb_feat [V,R,S,59], ray_diff [V,R,S,4], mask [V,R,S]
+        # -- any Projector's materialised tensors.  Same network kernel, inputs read instead of gathered (slower than the fused path, same results)
+        if rgb_feat is None or ray_diff is None or mask is None:
+            raise ValueError("o2345 GeneralRenderingNetwork.forward: pass a DeferredColour or the reference's four tensors")
+        R, S = geometry_feat.shape[:2]
+        V = rgb_feat.shape[0]
+        x3 = config.color_precision() == "f16x3"
+        rgb, nv = ops.color_from_features(self.x3_blob() if x3 else self.mfma_blob(), geometry_feat.reshape(R * S, -1), rgb_feat.reshape(V, R * S, -1),
+                                          ray_diff.reshape(V, R * S, 4), mask.reshape(V, R * S).float(), x3=x3)
+        valid = ((nv.view(R, S) >= 2).float().sum(1) > 8)
+        return rgb.view(R, S, 3), valid

@@ -245,6 +245,11 @@ def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=Non
     return rgb, nv
 
 
+def color_from_features(blob, geometry_feat, rgb_feat, ray_diff, mask, x3=True, want_nviews=True):
+    c, n = O.rendering_network(_COL[blob.data_ptr()], geometry_feat, rgb_feat, ray_diff, mask > 0)
+    return c, (n.to(torch.uint8) if want_nviews else None)
+
+
 def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64, inv_s=None, alpha_inter_ratio=1.0, background=1.0,
                 query_cam=None, want_z=False, t_rand=None):
     W, RW = _SDF[scene["sdf_blob"].data_ptr()], _COL[scene["color_blob"].data_ptr()]
@@ -289,7 +294,7 @@ def install(monkeypatch):
     costreg = importlib.import_module("one-2-3-45_amd.costreg")
     featurenet = importlib.import_module("one-2-3-45_amd.featurenet")
     for name in ("costvol_index", "costvol_gather", "visible_count_list", "costvol_gather_list", "build_index_grid", "scatter_dense", "sdf_mlp",
-                 "pack_color_maps", "color_points", "render_rays", "marching_cubes", "prune_dilate", "sparse_downsample", "sparse_conv3d", "bn_act_rows", "fpn_level", "pyramid_pack", "conv2d", "conv2d_pack", "conv_x3", "scale_shift_act"):
+                 "pack_color_maps", "color_points", "color_from_features", "render_rays", "marching_cubes", "prune_dilate", "sparse_downsample", "sparse_conv3d", "bn_act_rows", "fpn_level", "pyramid_pack", "conv2d", "conv2d_pack", "conv_x3", "scale_shift_act"):
         monkeypatch.setattr(ops, name, globals()[name])
     spnn = importlib.import_module("one-2-3-45_amd.shims.torchsparse.nn")
     monkeypatch.setattr(spnn, "_require_device", lambda t: None)

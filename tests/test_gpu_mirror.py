@@ -119,6 +119,32 @@ def test_vertex_colouring_like_trainer(S):
     assert rel(col.squeeze(0), g["vert_rgb"]) < 2e-4
 
 
+def test_rendering_network_on_materialised_tensors(S):
+    """GeneralRenderingNetwork.forward in the reference's own call form (geometry_feat [R,S,16], rgb_feat [V,R,S,59], ray_diff [V,R,S,4],
+    mask [V,R,S]; rendering_network.py:75-83) equals the fused path of our Projector on the same points."""
+    import sys
+    from oracle import recon as O
+    g, G, T = S["G"]["g"], S["G"], S["T"]
+    sc, HW = G["sc"], G["cfg"]["HW"]
+    dense, mask = T(g["dense"])[None], T(g["mask"])[None, None]
+    pts = torch.from_numpy(np.ascontiguousarray(g["vert_pts"])).float().reshape(-1, 3)
+    n = (pts.shape[0] // 12) * 12
+    pts = pts[:n]
+    a, b, c, d, _, _ = S["ren"].rendering_projector.compute(
+        T(pts.numpy()).view(-1, 12, 3), geometryVolume=dense[0], geometryVolumeMask=mask[0], rendering_feature_maps=T(G["fmaps"]),
+        color_maps=T(sc["images"]), w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW], query_img_idx=0, query_c2w=T(sc["query_c2w"])[None])
+    col_fused, valid_fused = S["rnet"](a, b, c, d)
+    fm, im = torch.from_numpy(G["fmaps"]), torch.from_numpy(sc["images"])
+    qcam = torch.from_numpy(np.ascontiguousarray(sc["query_c2w"][:3, 3]))
+    geo, rf, rd, vm = O.projector(pts, torch.from_numpy(g["dense"]), torch.from_numpy(g["mask"]), fm, im, torch.from_numpy(sc["w2cs"]),
+                                  torch.from_numpy(sc["intrinsics"]), (HW, HW), query_cam=qcam)
+    V = rf.shape[0]
+    col, valid = S["rnet"](T(geo.numpy()).view(-1, 12, 16), T(rf.contiguous().numpy()).view(V, -1, 12, 59), T(rd.contiguous().numpy()).view(V, -1, 12, 4),
+                           T(vm.float().numpy()).view(V, -1, 12))
+    assert col.shape == col_fused.shape and torch.equal(valid, valid_fused)
+    assert float((col - col_fused).abs().max()) < 2e-5
+
+
 def test_mcubes_shim(S):
     mcubes = importlib.import_module("one-2-3-45_amd.shims.mcubes")
     from oracle import mc as omc

@@ -142,6 +142,34 @@ def test_bn_and_abn(dev, ops):
         close(y2, ref.permute(0, 2, 3, 1), what=f"abn nhwc C={C}")
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "fp32"])
+@pytest.mark.parametrize("V", [4, 5])
+def test_color_from_materialised_features(dev, ops, prec, V):
+    """o2345_color_from_features = GeneralRenderingNetwork.forward on the reference's own four tensors (any Projector's output): against the oracle
+    network on the same tensors, and equal to the fused Projector + network kernel on the points those tensors were projected from."""
+    s = small_scene(V=V, HW=40, D=16) if V != 4 else small_scene()
+    d = dev_scene(s, dev, ops)
+    sc = s["sc"]
+    rng = np.random.default_rng(V)
+    pts = torch.from_numpy(rng.uniform(-0.9, 0.9, (1501, 3)).astype(np.float32))
+    pts[:20] = torch.tensor([1.5, 0.0, 0.0])
+    RW = color_t(s["color_sd"])
+    Kt, w2c = torch.from_numpy(sc["intrinsics"]), torch.from_numpy(sc["w2cs"])
+    fm, im = torch.from_numpy(s["fmaps"]), torch.from_numpy(sc["images"])
+    qcam = torch.from_numpy(sc["query_c2w"][:3, 3].copy())
+    geo, rf, rd, vm = O.projector(pts, s["dense"][0], s["mask"][0, 0], fm, im, w2c, Kt, (s["W"], s["H"]), query_cam=qcam)
+    rgb_ref, nv_ref = O.rendering_network(RW, geo, rf, rd, vm)
+    x3 = prec == "f16x3"
+    blob = d["color_x3_blob"] if x3 else d["color_mfma_blob"]
+    rgb, nv = ops.color_from_features(blob, geo.to(dev), rf.contiguous().to(dev), rd.contiguous().to(dev), vm.float().to(dev), x3=x3)
+    assert torch.equal(nv.cpu().float(), nv_ref)
+    close(rgb, rgb_ref, rel=1e-4, what="colour network on materialised tensors")
+    fused, _ = ops.color_points(blob, d["vol_cl"], d["maskvol"], d["cmaps"], d["proj"], d["cam_pos"], pts.to(dev), query_cam=qcam.to(dev), mfma="x3" if x3 else True)
+    close(rgb, fused, rel=2e-5, what="materialised vs fused inputs")
+    with pytest.raises(ValueError, match="expected geometry_feat"):
+        ops.color_from_features(blob, geo.to(dev), rf[..., :58].contiguous().to(dev), rd.contiguous().to(dev), vm.float().to(dev), x3=x3)
+
+
 CONV_SHAPES = [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1), (16, 32, 5, 2), (32, 32, 3, 1), (32, 32, 1, 1), (32, 16, 3, 1), (32, 8, 3, 1),
                (56, 16, 3, 1)]
 
