@@ -65,16 +65,19 @@ int o2345_pyramid_pack(const float* f2, const float* s1, const float* s0, const 
  * scale_shift_act: y = leaky_relu(x * scale + shift) for x [V,C,H,W], written as NCHW and / or channel-last NHWC (C = 8, 16, 32). */
 int o2345_conv2d_pack_weights(const float* w_oihw, int cout, int cin, int k, float* packed, void* stream);
 size_t o2345_conv2d_workspace_bytes(int V, int cout, int Ho, int Wo);
-int o2345_conv2d(const float* in, int V, int cin, int Hi, int Wi, const float* in_scale_shift, float slope, const float* w_packed,
-                 const float* bias, int cout, int k, int stride, float* out, const float* gamma, const float* beta, float eps, int abs_gamma,
-                 float* out_scale_shift, void* workspace, size_t workspace_bytes, void* stream);
-/* the same convolution on the matrix cores (split-f16 operands, fp32 accumulate: the default numerical mode); cin <= 64, cout <= 32;
+int o2345_conv2d(const float* in, int V, int cin, int Hi, int Wi, int in_pixel_stride, int in_channel_offset, const float* in_scale_shift, float slope,
+                 const float* w_packed, const float* bias, int cout, int k, int stride, float* out, const float* gamma, const float* beta, float eps,
+                 int abs_gamma, float* out_scale_shift, void* workspace, size_t workspace_bytes, void* stream);
+/* in_pixel_stride = 0: `in` is [V,cin,Hi,Wi] (channel-first).  in_pixel_stride > 0: `in` is a channel-last map [V,Hi,Wi,in_pixel_stride] and the
+ * convolution reads its channels in_channel_offset .. + cin (the compress layer reads the 56 features of the [V,H,W,64] colour map at offset 3, so the
+ * channel-first fused pyramid is never written on that path).
+ * the same convolution on the matrix cores (split-f16 operands, fp32 accumulate: the default numerical mode); cin <= 64, cout <= 32;
  * w_packed_x3 [conv2d_x3_weight_floats] from conv2d_pack_weights_x3 */
 size_t o2345_conv2d_x3_weight_floats(int cin, int k);
 int o2345_conv2d_pack_weights_x3(const float* w_oihw, int cout, int cin, int k, float* packed, void* stream);
-int o2345_conv2d_x3(const float* in, int V, int cin, int Hi, int Wi, const float* in_scale_shift, float slope, const float* w_packed_x3,
-                    const float* bias, int cout, int k, int stride, float* out, const float* gamma, const float* beta, float eps, int abs_gamma,
-                    float* out_scale_shift, void* workspace, size_t workspace_bytes, void* stream);
+int o2345_conv2d_x3(const float* in, int V, int cin, int Hi, int Wi, int in_pixel_stride, int in_channel_offset, const float* in_scale_shift, float slope,
+                    const float* w_packed_x3, const float* bias, int cout, int k, int stride, float* out, const float* gamma, const float* beta, float eps,
+                    int abs_gamma, float* out_scale_shift, void* workspace, size_t workspace_bytes, void* stream);
 int o2345_fpn_level_act(const float* fine, const float* fine_scale_shift, float slope, int c_in, const float* coarse, const float* weight,
                         const float* bias, int V, int H, int W, float* out, void* stream);
 int o2345_scale_shift_act(const float* x, int V, int C, int H, int W, const float* scale_shift, float slope, float* y_nchw, float* y_nhwc,

@@ -25,6 +25,9 @@ struct ConvArgs {
     double* part;             // [COUT][nblk][2] per-block sum / sum of squares, or null
     int nbx, nblk;            // tiles per row, tiles per view * views (set by the launcher)
     const float* gamma; const float* beta; float eps; int abs_gamma; float* out_ss;        // batch-norm parameters of this layer (statistics pass)
+    // input addressing: element (v, c, y, x) = in[v * view_stride + c * chan_stride + (y * Wi + x) * pix_stride]  (NCHW: Hi*Wi, 1; channel-last
+    // maps such as the [V,H,W,64] colour map with its features at channel 3: 1, 64, `in` already advanced by the channel offset)
+    long long view_stride, chan_stride; int pix_stride;
 };
 
 constexpr int CV_TX = 32, CV_TH = 8;          // threads of a block: 32 x 8; a thread owns PX horizontally adjacent output pixels
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void k_conv2d(ConvArgs a) {
     for (int p = 0; p < PX; ++p)
 #pragma unroll
         for (int co = 0; co < CPB; ++co) acc[p][co] = a.bias ? a.bias[cg * CPB + co] : 0.f;
-    const float* src = a.in + (size_t)v * CIN * a.Hi * a.Wi;
+    const float* src = a.in + (size_t)v * a.view_stride;
     const float* __restrict__ w = a.w + cg * CPB;
 #pragma unroll 1
     for (int c0 = 0; c0 < CIN; c0 += CC) {
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void k_conv2d(ConvArgs a) {
             const int gy = gy0 + iy, gx = gx0 + ix;
             float t = 0.f;                                                     // zero padding applies to the ACTIVATED input
             if (gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) {
-                t = src[((size_t)(c0 + c) * a.Hi + gy) * a.Wi + gx];
+                t = src[(size_t)(c0 + c) * a.chan_stride + ((size_t)gy * a.Wi + gx) * a.pix_stride];
                 if (a.in_ss) {
                     t = t * a.in_ss[c0 + c] + a.in_ss[CIN + c0 + c];
                     t = t >= 0.f ? t : t * a.slope;
@@ -233,8 +236,7 @@ __global__ __launch_bounds__(256) void k_conv2d_x3(ConvArgs a, int cin, int cout
     const int bx = blockIdx.x % a.nbx, by = blockIdx.x / a.nbx, v = blockIdx.y;
     const int ox = bx * 32 + j, oy0 = by * TH + wave * ROWS;
     const int gx0 = bx * 32 * STRIDE - PAD, gy0 = by * TH * STRIDE - PAD;
-    const size_t HW = (size_t)a.Hi * a.Wi;
-    const float* src = a.in + (size_t)v * cin * HW;
+    const float* src = a.in + (size_t)v * a.view_stride;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, K * K * NU * 2048, 0x00020000);
     float m1 = -1.f;
     asm volatile("" : "+v"(m1));                                                 // keeps fma(hi, -1, x) a v_fma_mix_f32 (see sdf_mlp_x3.hip)
@@ -251,14 +253,14 @@ __global__ __launch_bounds__(256) void k_conv2d_x3(ConvArgs a, int cin, int cout
         const int r = min((int)threadIdx.x + 256 * jj, NPIX - 1), iy = r / IW, ix = r % IW;
         const int gy = gy0 + iy, gx = gx0 + ix;
         pix_in[jj] = gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi;
-        pix_src[jj] = src + (size_t)min(max(gy, 0), a.Hi - 1) * a.Wi + min(max(gx, 0), a.Wi - 1);
+        pix_src[jj] = src + ((size_t)min(max(gy, 0), a.Hi - 1) * a.Wi + min(max(gx, 0), a.Wi - 1)) * a.pix_stride;
     }
     float pre[NLD][16];
     auto fetch = [&](int u) {                                                     // channel numbers are wave-uniform: scalar offsets
 #pragma unroll
         for (int jj = 0; jj < NLD; ++jj)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) pre[jj][t] = pix_src[jj][(size_t)min(16 * u + t, cin - 1) * HW];
+            for (int t = 0; t < 16; ++t) pre[jj][t] = pix_src[jj][(size_t)min(16 * u + t, cin - 1) * a.chan_stride];
     };
     fetch(0);
 #pragma unroll 1
@@ -410,10 +412,16 @@ size_t o2345_conv2d_workspace_bytes(int V, int cout, int Ho, int Wo) {
 // out = conv2d(act(in), w) (+ bias); act = leaky(in * scale + shift) when in_scale_shift is given.  padding = k / 2.
 // When gamma / beta / out_scale_shift are given, the batch statistics of `out` over (V, Ho, Wo) are reduced and out_scale_shift [2*cout] receives
 // the InPlaceABN (scale, shift) of this layer -- to be applied by the consumer (o2345_conv2d / o2345_fpn_level_act / o2345_scale_shift_act).
-int o2345_conv2d(const float* in, int V, int cin, int Hi, int Wi, const float* in_scale_shift, float slope, const float* w_packed, const float* bias,
-                 int cout, int k, int stride, float* out, const float* gamma, const float* beta, float eps, int abs_gamma, float* out_scale_shift,
-                 void* workspace, size_t workspace_bytes, void* stream) {
+static void set_input_layout(ConvArgs& a, int cin, int in_pixel_stride, int in_channel_offset) {
+    if (in_pixel_stride <= 0) { a.view_stride = (long long)cin * a.Hi * a.Wi; a.chan_stride = (long long)a.Hi * a.Wi; a.pix_stride = 1; }
+    else { a.view_stride = (long long)a.Hi * a.Wi * in_pixel_stride; a.chan_stride = 1; a.pix_stride = in_pixel_stride; a.in += in_channel_offset; }
+}
+
+int o2345_conv2d(const float* in, int V, int cin, int Hi, int Wi, int in_pixel_stride, int in_channel_offset, const float* in_scale_shift, float slope,
+                 const float* w_packed, const float* bias, int cout, int k, int stride, float* out, const float* gamma, const float* beta, float eps,
+                 int abs_gamma, float* out_scale_shift, void* workspace, size_t workspace_bytes, void* stream) {
     O2345_REQUIRE(in && w_packed && out && V >= 1 && Hi >= 1 && Wi >= 1, "conv2d: bad arguments");
+    O2345_REQUIRE(in_pixel_stride <= 0 || (in_channel_offset >= 0 && in_channel_offset + cin <= in_pixel_stride), "conv2d: channel-last input: offset + cin must fit the pixel stride");
     O2345_REQUIRE(stride == 1 || stride == 2, "conv2d: stride 1 or 2 (got %d)", stride);
     const int pad = k / 2;
     const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
@@ -422,8 +430,9 @@ int o2345_conv2d(const float* in, int V, int cin, int Hi, int Wi, const float* i
         O2345_REQUIRE(gamma && beta && workspace, "conv2d: batch statistics need gamma, beta and a workspace");
         O2345_REQUIRE(workspace_bytes >= o2345_conv2d_workspace_bytes(V, cout, Ho, Wo), "conv2d: workspace too small");
     }
-    const ConvArgs a{in, in_scale_shift, slope, w_packed, bias, Hi, Wi, Ho, Wo, out, stats ? (double*)workspace : nullptr, 0, 0,
-                     gamma, beta, eps, abs_gamma, out_scale_shift};
+    ConvArgs a{in, in_scale_shift, slope, w_packed, bias, Hi, Wi, Ho, Wo, out, stats ? (double*)workspace : nullptr, 0, 0,
+               gamma, beta, eps, abs_gamma, out_scale_shift, 0, 0, 0};
+    set_input_layout(a, cin, in_pixel_stride, in_channel_offset);
     hipStream_t s = (hipStream_t)stream;
     // pixels per thread / output channels per block by map size, so that a launch covers the chip (1024 SIMDs) a few times over:
     // 4 pixels x <= 16 channels on large maps (most FMAs per scalar weight load), 1 pixel x 8 channels on small ones
@@ -462,10 +471,11 @@ int o2345_conv2d_pack_weights_x3(const float* w_oihw, int cout, int cin, int k, 
 }
 
 // the same function as o2345_conv2d on the matrix cores (split-f16, fp32 accumulate); w_packed_x3 from o2345_conv2d_pack_weights_x3
-int o2345_conv2d_x3(const float* in, int V, int cin, int Hi, int Wi, const float* in_scale_shift, float slope, const float* w_packed_x3, const float* bias,
-                    int cout, int k, int stride, float* out, const float* gamma, const float* beta, float eps, int abs_gamma, float* out_scale_shift,
-                    void* workspace, size_t workspace_bytes, void* stream) {
+int o2345_conv2d_x3(const float* in, int V, int cin, int Hi, int Wi, int in_pixel_stride, int in_channel_offset, const float* in_scale_shift, float slope,
+                    const float* w_packed_x3, const float* bias, int cout, int k, int stride, float* out, const float* gamma, const float* beta, float eps,
+                    int abs_gamma, float* out_scale_shift, void* workspace, size_t workspace_bytes, void* stream) {
     O2345_REQUIRE(in && w_packed_x3 && out && V >= 1 && Hi >= 1 && Wi >= 1, "conv2d_x3: bad arguments");
+    O2345_REQUIRE(in_pixel_stride <= 0 || (in_channel_offset >= 0 && in_channel_offset + cin <= in_pixel_stride), "conv2d_x3: channel-last input: offset + cin must fit the pixel stride");
     O2345_REQUIRE(cout >= 1 && cout <= 32 && cin >= 1 && cin <= 64, "conv2d_x3: at most 64 input and 32 output channels (got %d -> %d)", cin, cout);
     const int pad = k / 2;
     const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
@@ -474,8 +484,9 @@ int o2345_conv2d_x3(const float* in, int V, int cin, int Hi, int Wi, const float
         O2345_REQUIRE(gamma && beta && workspace, "conv2d_x3: batch statistics need gamma, beta and a workspace");
         O2345_REQUIRE(workspace_bytes >= o2345_conv2d_workspace_bytes(V, cout, Ho, Wo), "conv2d_x3: workspace too small");
     }
-    const ConvArgs a{in, in_scale_shift, slope, w_packed_x3, bias, Hi, Wi, Ho, Wo, out, stats ? (double*)workspace : nullptr, 0, 0,
-                     gamma, beta, eps, abs_gamma, out_scale_shift};
+    ConvArgs a{in, in_scale_shift, slope, w_packed_x3, bias, Hi, Wi, Ho, Wo, out, stats ? (double*)workspace : nullptr, 0, 0,
+               gamma, beta, eps, abs_gamma, out_scale_shift, 0, 0, 0};
+    set_input_layout(a, cin, in_pixel_stride, in_channel_offset);
     hipStream_t s = (hipStream_t)stream;
     const int cinp = (cin + 15) / 16 * 16;
     bool done = true;

@@ -60,41 +60,57 @@ __global__ __launch_bounds__(256) void k_fpn_level(const float* __restrict__ fin
     }
 }
 
-// grid (ceil(H*W / 256), V); one thread per pixel.  fmaps_nchw may be null.
+// grid (ceil(H*W / 256), V); one thread per pixel.  fmaps_nchw may be null.  The channel-last pixel (256 bytes) is not written by its own thread
+// (64 lanes x 16 bytes at a 256-byte stride = 64 cache lines per store instruction) but through a per-wave LDS transpose in two halves of 32
+// channels: a store instruction then covers 8 pixels x 128 contiguous bytes (8 full lines).
 __global__ __launch_bounds__(256) void k_pyramid_pack(const float* __restrict__ f2 /*[V,32,H/4,W/4]*/, const float* __restrict__ s1 /*[V,16,H/2,W/2]*/,
                                                        const float* __restrict__ s0 /*[V,8,H,W]*/, const float* __restrict__ rgb /*[V,3,H,W]*/, int H, int W,
                                                        float* __restrict__ fmaps_nchw /*[V,56,H,W]*/, float* __restrict__ cmaps /*[V,H,W,64]*/) {
-    const int p = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
-    if (p >= H * W) return;
-    const int y = p / W, x = p % W, HW = H * W;
+    __shared__ float tr[4][64][33];
+    const int p = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, HW = H * W;
+    const bool live = p < HW;
+    const int pc = live ? p : HW - 1;
+    const int y = pc / W, x = pc % W;
     float px[64];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) px[c] = rgb[((size_t)v * 3 + c) * HW + p];
+    for (int c = 0; c < 3; ++c) px[c] = rgb[((size_t)v * 3 + c) * HW + pc];
     {
         const int h4 = H / 4, w4 = W / 4;
         const Lerp ly = up_coord(y, h4, H), lx = up_coord(x, w4, W);
         const float* b = f2 + (size_t)v * 32 * h4 * w4;
-#pragma unroll 4
+#pragma unroll
         for (int c = 0; c < 32; ++c) px[3 + c] = bilerp(b + (size_t)c * h4 * w4, w4, ly, lx);
     }
     {
         const int h2 = H / 2, w2 = W / 2;
         const Lerp ly = up_coord(y, h2, H), lx = up_coord(x, w2, W);
         const float* b = s1 + (size_t)v * 16 * h2 * w2;
-#pragma unroll 4
+#pragma unroll
         for (int c = 0; c < 16; ++c) px[35 + c] = bilerp(b + (size_t)c * h2 * w2, w2, ly, lx);
     }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) px[51 + c] = s0[((size_t)v * 8 + c) * HW + p];
+    for (int c = 0; c < 8; ++c) px[51 + c] = s0[((size_t)v * 8 + c) * HW + pc];
 #pragma unroll
     for (int c = 59; c < 64; ++c) px[c] = 0.f;
-    if (fmaps_nchw) {
+    if (fmaps_nchw && live) {
 #pragma unroll
         for (int c = 0; c < 56; ++c) fmaps_nchw[((size_t)v * 56 + c) * HW + p] = px[3 + c];
     }
-    float4* o = reinterpret_cast<float4*>(cmaps + ((size_t)v * HW + p) * 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p0 = blockIdx.x * 256 + wave * 64;                       // first pixel of this wave
+    float* dst = cmaps + ((size_t)v * HW + p0) * 64;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) o[q] = make_float4(px[4 * q], px[4 * q + 1], px[4 * q + 2], px[4 * q + 3]);
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) tr[wave][lane][c] = px[32 * half + c];
+        // (one wave writes and reads its own tile: no workgroup barrier needed, the LDS operations of a wave complete in order)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int pp = q * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+            const float4 t = make_float4(tr[wave][pp][c4], tr[wave][pp][c4 + 1], tr[wave][pp][c4 + 2], tr[wave][pp][c4 + 3]);
+            if (p0 + pp < HW) *reinterpret_cast<float4*>(dst + (size_t)pp * 64 + 32 * half + c4) = t;
+        }
+    }
 }
 
 }  // namespace o2345

@@ -55,19 +55,21 @@ class ConvBnReLU(nn.Module):
         self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False)
         self.bn = InPlaceABN(cout)
 
-    def raw(self, x, in_scale_shift=None):
-        """-> (raw conv output, this layer's ABN (scale | shift)); ``in_scale_shift``: x is itself a raw output to be activated on load."""
+    def raw(self, x, in_scale_shift=None, nhwc_offset=None):
+        """-> (raw conv output, this layer's ABN (scale | shift)); ``in_scale_shift``: x is itself a raw output to be activated on load;
+        ``nhwc_offset``: x is a channel-last map whose channels nhwc_offset .. + cin are the input."""
         bn = self.bn                                      # ops.conv2d raises for CPU tensors: there is no CPU fallback
         return ops.conv2d(x.contiguous().float(), self.conv.weight.detach(), None, self.conv.stride[0], in_scale_shift, bn.slope,
-                          bn=(bn.weight.detach(), bn.bias.detach(), bn.eps, bn.abs_gamma), packed=packed_weight(self.conv))
+                          bn=(bn.weight.detach(), bn.bias.detach(), bn.eps, bn.abs_gamma), packed=packed_weight(self.conv), nhwc_offset=nhwc_offset)
 
     def forward(self, x):
         r, ss = self.raw(x)
         return ops.scale_shift_act(r, ss, self.bn.slope)[0]
 
-    def forward_nhwc(self, x):
-        """The activated output as a channel-last map [V,H,W,C] (what the cost-volume gather reads)."""
-        r, ss = self.raw(x)
+    def forward_nhwc(self, x, nhwc_offset=None):
+        """The activated output as a channel-last map [V,H,W,C] (what the cost-volume gather reads).  ``nhwc_offset``: the INPUT is channel-last too
+        (the [V,H,W,64] colour map, features at channel 3)."""
+        r, ss = self.raw(x, nhwc_offset=nhwc_offset)
         return ops.scale_shift_act(r, ss, self.bn.slope, want_nchw=False, want_nhwc=True)[1]
 
 
@@ -103,9 +105,10 @@ class FeatureNet(nn.Module):
         return [f2, s1, s0]
 
 
-def fused_pyramid(extractor, imgs, want_cmaps=False):
+def fused_pyramid(extractor, imgs, want_cmaps=False, want_nchw=True):
     """trainer_generic.py:1104-1125: [V,3,H,W] -> fused pyramid [V,56,H,W] (+ the channel-last colour map [V,H,W,64] = rgb | features | pad when
-    want_cmaps): both written by ONE kernel (csrc/featmaps.hip) instead of two F.interpolate, a cat and a re-layout pass."""
+    want_cmaps): both written by ONE kernel (csrc/featmaps.hip) instead of two F.interpolate, a cat and a re-layout pass.  want_nchw=False skips the
+    channel-first tensor (the pipeline's compress layer reads the features out of the colour map)."""
     f2, s1, s0 = extractor(imgs)
-    fm, cm = ops.pyramid_pack(f2.contiguous(), s1.contiguous(), s0.contiguous(), imgs.contiguous().float())
+    fm, cm = ops.pyramid_pack(f2.contiguous(), s1.contiguous(), s0.contiguous(), imgs.contiguous().float(), want_nchw=want_nchw)
     return (fm, cm) if want_cmaps else fm

@@ -104,16 +104,25 @@ def conv2d_pack(weight, precision=None):
 
 
 @_on_device
-def conv2d(x, weight, bias=None, stride=1, in_scale_shift=None, slope=0.01, bn=None, packed=None, precision=None):
+def conv2d(x, weight, bias=None, stride=1, in_scale_shift=None, slope=0.01, bn=None, packed=None, precision=None, nhwc_offset=None):
     """nn.Conv2d (padding k // 2) of FeatureNet / the compress layer as a HIP kernel (csrc/convnet.hip): implicit GEMM on the matrix cores in the
     default mode, direct fp32 VALU convolution in fp32 mode.
     ``in_scale_shift`` [2*cin]: x is the RAW output of a convolution whose InPlaceABN (scale | shift, leaky ``slope``) is applied while x is read.
     ``bn`` = (gamma, beta, eps, abs_gamma): also reduce the batch statistics of the output and return this layer's own (scale | shift) [2*cout]
-    for the consumer to apply.  ``packed``: conv2d_pack(weight, precision) kept by the caller.  -> (raw output [V,cout,Ho,Wo], scale_shift or None)."""
-    V, cin, Hi, Wi = x.shape
-    cout, cin_w, k, _ = weight.shape
-    if cin_w != cin:
-        raise ValueError(f"conv2d: weight expects {cin_w} input channels, got {cin}")
+    for the consumer to apply.  ``packed``: conv2d_pack(weight, precision) kept by the caller.  ``nhwc_offset`` = c0: x is a channel-last map
+    [V,Hi,Wi,C] and the convolution reads its channels c0 .. c0 + cin (the compress layer on the [V,H,W,64] colour map, c0 = 3).
+    -> (raw output [V,cout,Ho,Wo], scale_shift or None)."""
+    cout, cin, k, _ = weight.shape
+    if nhwc_offset is None:
+        V, cx, Hi, Wi = x.shape
+        pix_stride, c0 = 0, 0
+        if cx != cin:
+            raise ValueError(f"conv2d: weight expects {cin} input channels, got {cx}")
+    else:
+        V, Hi, Wi, pix_stride = x.shape
+        c0 = int(nhwc_offset)
+        if c0 < 0 or c0 + cin > pix_stride:
+            raise ValueError(f"conv2d: channels {c0}..{c0 + cin} do not fit a channel-last map with {pix_stride} channels")
     pad = k // 2
     Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
     L = _lib.lib()
@@ -126,7 +135,7 @@ def conv2d(x, weight, bias=None, stride=1, in_scale_shift=None, slope=0.01, bn=N
         wsb = L.o2345_conv2d_workspace_bytes(V, cout, Ho, Wo)
         ws = _workspace(wsb, x.device, "conv2d")
     fn = L.o2345_conv2d_x3 if conv_x3(precision) else L.o2345_conv2d
-    check(fn(_p(x), V, cin, Hi, Wi, _p(in_scale_shift), float(slope), _p(packed if packed is not None else conv2d_pack(weight, precision)),
+    check(fn(_p(x), V, cin, Hi, Wi, int(pix_stride), c0, _p(in_scale_shift), float(slope), _p(packed if packed is not None else conv2d_pack(weight, precision)),
              _p(None if bias is None else _f(bias)), cout, k, int(stride), _p(out), _p(None if gamma is None else _f(gamma)),
              _p(None if beta is None else _f(beta)), float(eps), int(abs_gamma), _p(ss), _p(ws, torch.uint8), wsb, _stream()), "conv2d")
     return out, ss

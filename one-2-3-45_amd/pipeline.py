@@ -67,8 +67,12 @@ def build_volume(wt, imgs, affine_mats, origin, D, voxel_size, fmaps=None):
     V, _, H, W = imgs.shape
     cmaps = None
     if fmaps is None:
-        fmaps, cmaps = fused_pyramid(wt.featurenet, imgs, want_cmaps=True)     # [V,56,H,W] + [V,H,W,64]: HIP convolutions / FPN / pyramid kernels
-    feats_nhwc = wt.compress.forward_nhwc(fmaps)                               # Conv3x3 56->16 + batch stats, then ABN + channel-last re-layout (HIP)
+        # the fused pyramid is written once, as the channel-last colour map [V,H,W,64] (rgb | 56 features | pad); the compress layer reads its
+        # features from there (channel offset 3): the channel-first [V,56,H,W] tensor of the reference API is never materialised on this path
+        _, cmaps = fused_pyramid(wt.featurenet, imgs, want_cmaps=True, want_nchw=False)
+        feats_nhwc = wt.compress.forward_nhwc(cmaps, nhwc_offset=3)            # Conv3x3 56->16 + batch stats, then ABN + channel-last re-layout (HIP)
+    else:
+        feats_nhwc = wt.compress.forward_nhwc(fmaps)
     cnt, row, coords, n = ops.costvol_index(affine_mats, V, H, W, (D, D, D), voxel_size, origin)
     rows = ops.costvol_gather(feats_nhwc, affine_mats, (D, D, D), voxel_size, origin, cnt, coords)
     rows16 = wt.costreg.forward(rows, coords, row, (D, D, D))

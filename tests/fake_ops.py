@@ -94,8 +94,10 @@ def conv2d_pack(weight, precision=None):
     return weight
 
 
-def conv2d(x, weight, bias=None, stride=1, in_scale_shift=None, slope=0.01, bn=None, packed=None, precision=None):
+def conv2d(x, weight, bias=None, stride=1, in_scale_shift=None, slope=0.01, bn=None, packed=None, precision=None, nhwc_offset=None):
     """ops.conv2d: raw convolution output + this layer's InPlaceABN (scale | shift) from the batch statistics."""
+    if nhwc_offset is not None:
+        x = x[..., nhwc_offset:nhwc_offset + weight.shape[1]].permute(0, 3, 1, 2)
     if in_scale_shift is not None:
         x = _ss_act(x, in_scale_shift, slope)
     out = F.conv2d(x, weight, bias, stride, weight.shape[-1] // 2)

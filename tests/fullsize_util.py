@@ -51,7 +51,7 @@ def _oracle_args(full):
     mask = vol["maskvol"].view(D, D, D).cpu()
     W = {k: torch.from_numpy(np.asarray(v)) for k, v in wt.sdfW.items()}
     RW = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in wt.color_sd.items()}
-    fm = vol["fmaps"].cpu()
+    fm = (vol["fmaps"] if vol["fmaps"] is not None else vol["cmaps"][..., 3:59].permute(0, 3, 1, 2)).contiguous().cpu()   # the pipeline keeps the channel-last map only
     H, Wd = sc["images"].shape[2:]
     return dict(volume=dense, maskvol=mask, W=W, RW=RW, variance=torch.tensor(wt.variance, dtype=torch.float32), feat_maps=fm,
                 color_maps=torch.from_numpy(sc["images"]), w2cs=torch.from_numpy(sc["w2cs"]), K=torch.from_numpy(sc["intrinsics"]),

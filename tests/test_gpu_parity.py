@@ -211,6 +211,31 @@ def test_conv2d_vs_torch(dev, ops, cin, cout, k, stride, hw, prec):
         assert torch.equal(y2, y1.permute(0, 2, 3, 1))
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "fp32"])
+def test_conv2d_channel_last_input(dev, ops, prec):
+    """The compress layer reading its 56 input channels out of the channel-last colour map [V,H,W,64] (offset 3) == the same convolution on the
+    channel-first tensor, bit for bit (same kernel, other addressing), and the pyramid kernel's channel-last output carries those features."""
+    rng = np.random.default_rng(5)
+    V, H, W = 3, 24, 44
+    cm = torch.from_numpy(rng.normal(0, 1, (V, H, W, 64)).astype(np.float32)).to(dev)
+    x = cm[..., 3:59].permute(0, 3, 1, 2).contiguous()
+    w = torch.from_numpy((rng.normal(0, 1, (16, 56, 3, 3)) / 22).astype(np.float32)).to(dev)
+    g = torch.from_numpy(rng.uniform(0.5, 1.5, 16).astype(np.float32)).to(dev); b = torch.from_numpy(rng.normal(0, 0.2, 16).astype(np.float32)).to(dev)
+    y0, ss0 = ops.conv2d(x, w, bn=(g, b, 1e-5, True), precision=prec)
+    y1, ss1 = ops.conv2d(cm, w, bn=(g, b, 1e-5, True), precision=prec, nhwc_offset=3)
+    assert torch.equal(y0, y1) and torch.equal(ss0, ss1)
+    with pytest.raises(ValueError, match="do not fit"):
+        ops.conv2d(cm, w, precision=prec, nhwc_offset=9)
+    # k_pyramid_pack: channel-last map alone (no channel-first tensor) == the map written together with it
+    f2 = torch.from_numpy(rng.normal(0, 1, (V, 32, H // 4, W // 4)).astype(np.float32)).to(dev)
+    s1 = torch.from_numpy(rng.normal(0, 1, (V, 16, H // 2, W // 2)).astype(np.float32)).to(dev)
+    s0 = torch.from_numpy(rng.normal(0, 1, (V, 8, H, W)).astype(np.float32)).to(dev)
+    rgb = torch.from_numpy(rng.uniform(0, 1, (V, 3, H, W)).astype(np.float32)).to(dev)
+    fm, cm2 = ops.pyramid_pack(f2, s1, s0, rgb)
+    none, cm3 = ops.pyramid_pack(f2, s1, s0, rgb, want_nchw=False)
+    assert none is None and torch.equal(cm2, cm3) and torch.equal(cm2[..., 3:59].permute(0, 3, 1, 2), fm) and torch.equal(cm2[..., :3].permute(0, 3, 1, 2), rgb)
+
+
 def test_conv2d_rejects_other_shapes(dev, ops):
     with pytest.raises(Exception, match="no kernel for"):
         ops.conv2d(torch.zeros(1, 4, 8, 8, device=dev), torch.zeros(8, 4, 3, 3, device=dev), precision="fp32")
