@@ -158,6 +158,13 @@ int o2345_sdf_mlp_x3(const float* blob, const float* vol_cl, int D, const float*
 /* SDF + analytic gradient, wide layers (144->128 and its transpose) split-f16, the 40-wide layer 0 on the exact fp32 MFMA */
 int o2345_sdf_grad_x3(const float* blob, const float* vol_cl, int D, const float* pts, const int32_t* index, const int32_t* n_dev,
                       long long n, int grid_R, float sign, float* out_sdf, float* out_grad, void* stream);
+/* extract_fields on the lattice with layer 0 of the SDF network TABULATED (ABI 1.3): on the x-major lattice linspace(-1,1,R)^3 the first layer's
+ * pre-activation is separable, b0 + W0 . PE(x,y,z) = Txy[ix,iy] + Tz[iz].  tab_axes [3][R][128]: per-axis tables in the kernels' lane order
+ * (weights.sdf_grid_tables); sdf_grid_tables adds x + y + bias into tab_xy [R*R][128]; sdf_grid_x3 evaluates out_sdf [R^3] = sign * sdf with
+ * tab_xy and tab_z = tab_axes + 2*R*128.  Same network as o2345_sdf_mlp_x3 with pts = NULL, grid_R = R, minus 18 sincos and 36 matrix steps per tile. */
+int o2345_sdf_grid_tables(const float* tab_axes, const float* bias_lane_order, int grid_R, float* tab_xy, void* stream);
+int o2345_sdf_grid_x3(const float* blob, const float* vol_cl, int D, int grid_R, float sign, const float* tab_xy, const float* tab_z,
+                      float* out_sdf, void* stream);
 
 /* ---- ray rendering (replaces models/sparse_neus_renderer.py:457 render and everything it calls) ------------------
  * Per-sample arrays are sample-major [S][R]. */

@@ -54,6 +54,10 @@ struct SdfArgs {
     float* out_lat;           // [P,16] or null
     float* out_grad;          // [P,3] or null (VAR_GRAD)
     const float* lat_in;      // optional [P,16]: use this latent instead of sampling the volume (get_sdf_volume)
+    // lattice mode of k_sdf_mlp_x3 only: layer 0 tabulated per axis (weights.sdf_grid_tables): its pre-activation is separable on the lattice,
+    // a0(ix,iy,iz) = b0 + Tx[ix] + Ty[iy] + Tz[iz]; rows of 128 floats in lane order [wave half][accumulator block * 16 + register]
+    const float* tab_xy;      // [R*R][128] = b0 + Tx[ix] + Ty[iy]
+    const float* tab_z;       // [R][128]
 };
 
 // Softplus(beta=100, threshold=20) and its derivative (torch: x if 100x > 20 else log1p(exp(100x))/100; backward

@@ -67,6 +67,10 @@ __device__ __forceinline__ void mma_x3(f32x16 (&acc)[NB], const float4* A, int l
     }
 }
 
+// TAB: the points are the x-major lattice linspace(-1,1,R)^3 (extract_fields) and layer 0 comes from per-axis tables: the positional encoding is
+// separable, so W0 . PE(x,y,z) + b0 = Txy[ix,iy] + Tz[iz] -- two 256-byte row reads and 64 adds per lane replace 18 sincos evaluations, the operand
+// split of the encoding and the 36 matrix steps of layer 0 (tables in fp64-evaluated fp32: more accurate than the split-f16 products they replace).
+template <bool TAB>
 __global__ __launch_bounds__(512) void k_sdf_mlp_x3(SdfArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int N_A0 = 4 * STX0 * 2 * 256, N_A1 = 4 * STH1 * 2 * 256;
@@ -90,13 +94,14 @@ __global__ __launch_bounds__(512) void k_sdf_mlp_x3(SdfArgs a) {
         const bool live = i < n;
         long long slot = live ? (a.index ? (long long)a.index[i] : i) : 0;
         float px, py, pz;
-        if (a.pts) {
+        int ix = 0, iy = 0, iz = 0;
+        if (!TAB && a.pts) {
             px = live ? a.pts[slot * 3 + 0] : 0.f; py = live ? a.pts[slot * 3 + 1] : 0.f; pz = live ? a.pts[slot * 3 + 2] : 0.f;
         } else {
             const int R = a.R;
             const unsigned us = (unsigned)slot, uR = (unsigned)R;          // R^3 < 2^32: 32-bit divisions (the 64-bit ones cost 240 instructions)
             const unsigned uq = us / uR;
-            const int iz = (int)(us - uq * uR), ix = (int)(uq / uR), iy = (int)(uq - (uq / uR) * uR);
+            iz = (int)(us - uq * uR); ix = (int)(uq / uR); iy = (int)(uq - (uq / uR) * uR);
             px = lin11(ix, R); py = lin11(iy, R); pz = lin11(iz, R);
         }
         // ---- trilinear latent: this half's 8 channels (reference edge semantics) ---------------------------------------------
@@ -122,28 +127,41 @@ __global__ __launch_bounds__(512) void k_sdf_mlp_x3(SdfArgs a) {
                         }
             }
         }
-        // ---- positional encoding: this half's 20 slots (+4 zero pads to fill three k steps) -------------------------------------
-        float pe[24];
-        const float p3[3] = {px, py, pz};
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int c = 9 * h + t;
-            const float f = (float)(1 << (c / 3));
-            float s, co;
-            sincos_pe(p3[t % 3] * f, s, co);
-            pe[t] = s; pe[9 + t] = co;
-        }
-        pe[18] = h ? pz : px;
-        pe[19] = h ? 0.f : py;
-        pe[20] = pe[21] = pe[22] = pe[23] = 0.f;
-        // ---- layer 0 -------------------------------------------------------------------------------------------------------------------
         f32x16 acc[4];
+        if constexpr (TAB) {
+            // ---- layer 0 from the tables ------------------------------------------------------------------------------------------------------
+            const float4* txy = reinterpret_cast<const float4*>(a.tab_xy + ((size_t)ix * a.R + iy) * 128 + 64 * h);
+            const float4* tz = reinterpret_cast<const float4*>(a.tab_z + (size_t)iz * 128 + 64 * h);
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+            for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] = misc[MISC_B0 + (nb * 16 + r) * 2 + h];
+                for (int q = 0; q < 4; ++q) {
+                    const float4 u = txy[nb * 4 + q], w = tz[nb * 4 + q];
+                    acc[nb][4 * q] = u.x + w.x; acc[nb][4 * q + 1] = u.y + w.y; acc[nb][4 * q + 2] = u.z + w.z; acc[nb][4 * q + 3] = u.w + w.w;
+                }
+        } else {
+            // ---- positional encoding: this half's 20 slots (+4 zero pads to fill three k steps) -------------------------------------
+            float pe[24];
+            const float p3[3] = {px, py, pz};
 #pragma unroll
-        for (int s = 0; s < STX0; ++s) mma_x3<4, STX0>(acc, A0, lane, s, split8(pe + 8 * s, m1));
+            for (int t = 0; t < 9; ++t) {
+                const int c = 9 * h + t;
+                const float f = (float)(1 << (c / 3));
+                float s, co;
+                sincos_pe(p3[t % 3] * f, s, co);
+                pe[t] = s; pe[9 + t] = co;
+            }
+            pe[18] = h ? pz : px;
+            pe[19] = h ? 0.f : py;
+            pe[20] = pe[21] = pe[22] = pe[23] = 0.f;
+            // ---- layer 0 -------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nb][r] = misc[MISC_B0 + (nb * 16 + r) * 2 + h];
+#pragma unroll
+            for (int s = 0; s < STX0; ++s) mma_x3<4, STX0>(acc, A0, lane, s, split8(pe + 8 * s, m1));
+        }
         Split8 hb[8];                   // softplus(layer 0), split, as the 8 hidden k-step operands of layer 1
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
@@ -465,16 +483,47 @@ int o2345_sdf_mlp_x3(const float* blob, const float* vol_cl, int D, const float*
     O2345_REQUIRE(D >= 2, "sdf_mlp_x3: bad volume side %d", D);
     O2345_REQUIRE(pts || (grid_R >= 2 && grid_R <= 1600), "sdf_mlp_x3: need points or a grid resolution in [2, 1600]");
     if (n <= 0 && !n_dev) return 0;
-    SdfArgs a{blob, vol_cl, D, pts, index, n_dev, n, grid_R, sign, out_sdf, nullptr, nullptr, nullptr, nullptr};
+    SdfArgs a{blob, vol_cl, D, pts, index, n_dev, n, grid_R, sign, out_sdf, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const int n_cu = cu_count();
     const int threads = 512;
     const long long per_block = (threads / 64) * 32;
     long long want = n_dev ? n_cu : (n + per_block - 1) / per_block;
     const unsigned grid = persistent_grid(want, n_cu);
     const size_t lds_bytes = (size_t)(4 * STX0 * 2 * 256 + 4 * STH1 * 2 * 256 + MISC_SIZE) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)k_sdf_mlp_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(k_sdf_mlp_x3, dim3(grid), dim3(threads), lds_bytes, (hipStream_t)stream, a);
+    (void)hipFuncSetAttribute((const void*)k_sdf_mlp_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(k_sdf_mlp_x3<false>, dim3(grid), dim3(threads), lds_bytes, (hipStream_t)stream, a);
     return check_launch("sdf_mlp_x3");
+}
+
+// tab_xy[(ix * R + iy)][c] = tab_axes[0][ix][c] + tab_axes[1][iy][c] + bias[c]   (c = 128 lane-ordered columns; summed in doubles)
+__global__ __launch_bounds__(128) void k_sdf_tab_xy(const float* __restrict__ axes /*[3][R][128]*/, const float* __restrict__ bias /*[128]*/, int R,
+                                                     float* __restrict__ tab_xy) {
+    const int c = threadIdx.x, ix = blockIdx.x / R, iy = blockIdx.x % R;
+    tab_xy[(size_t)blockIdx.x * 128 + c] = (float)((double)axes[(size_t)ix * 128 + c] + (double)axes[((size_t)R + iy) * 128 + c] + (double)bias[c]);
+}
+
+int o2345_sdf_grid_tables(const float* tab_axes, const float* bias_lane_order, int grid_R, float* tab_xy, void* stream) {
+    O2345_REQUIRE(tab_axes && bias_lane_order && tab_xy && grid_R >= 2 && grid_R <= 1600, "sdf_grid_tables: bad arguments");
+    hipLaunchKernelGGL(k_sdf_tab_xy, dim3(grid_R * grid_R), dim3(128), 0, (hipStream_t)stream, tab_axes, bias_lane_order, grid_R, tab_xy);
+    return check_launch("sdf_grid_tables");
+}
+
+// extract_fields (sparse_neus_renderer.py:881-905) with layer 0 of the SDF network read from per-axis tables: out_sdf[R^3] = sign * sdf on the
+// x-major lattice linspace(-1,1,R)^3.  tab_xy [R*R,128] from o2345_sdf_grid_tables, tab_z [R,128] = the z table (tab_axes + 2*R*128).
+int o2345_sdf_grid_x3(const float* blob, const float* vol_cl, int D, int grid_R, float sign, const float* tab_xy, const float* tab_z, float* out_sdf,
+                      void* stream) {
+    O2345_REQUIRE(blob && vol_cl && out_sdf && tab_xy && tab_z, "sdf_grid_x3: null pointer");
+    O2345_REQUIRE(D >= 2 && grid_R >= 2 && grid_R <= 1600, "sdf_grid_x3: bad sizes");
+    const long long n = (long long)grid_R * grid_R * grid_R;
+    SdfArgs a{blob, vol_cl, D, nullptr, nullptr, nullptr, n, grid_R, sign, out_sdf, nullptr, nullptr, nullptr, nullptr, tab_xy, tab_z};
+    const int n_cu = cu_count();
+    const int threads = 512;
+    const long long per_block = (threads / 64) * 32;
+    const unsigned grid = persistent_grid((n + per_block - 1) / per_block, n_cu);
+    const size_t lds_bytes = (size_t)(4 * STX0 * 2 * 256 + 4 * STH1 * 2 * 256 + MISC_SIZE) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)k_sdf_mlp_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(k_sdf_mlp_x3<true>, dim3(grid), dim3(threads), lds_bytes, (hipStream_t)stream, a);
+    return check_launch("sdf_grid_x3");
 }
 
 }  // extern "C"

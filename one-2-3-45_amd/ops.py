@@ -344,11 +344,21 @@ def abn_nchw(x, gamma, beta, eps=1e-5, slope=0.01, abs_gamma=True, want_nchw=Tru
 
 # ---------------------------------------------------------------------------------------------------------- SDF network
 @_on_device
+def sdf_grid_tables(tab_axes, bias_lane_order):
+    """(tab_axes [3,R,128], bias [128]) from weights.sdf_grid_tables, on the device -> (tab_xy [R*R,128] = x + y + bias, tab_z [R,128])."""
+    R = tab_axes.shape[1]
+    tab_xy = torch.empty(R * R, 128, dtype=torch.float32, device=tab_axes.device)
+    check(_lib.lib().o2345_sdf_grid_tables(_p(tab_axes), _p(bias_lane_order), R, _p(tab_xy), _stream()), "sdf_grid_tables")
+    return tab_xy, tab_axes[2]
+
+
+@_on_device
 def sdf_mlp(blob, vol_cl, pts=None, variant=0, grid_R=0, sign=1.0, index=None, n_dev=None, want_lat=False, out=None, lat_in=None,
-            precision=None):
+            precision=None, grid_tables=None):
     """variant 0: sdf; 1: sdf + 128 features; 2: sdf + gradient.  pts [P,3] or grid_R.  lat_in [P,16]: given latents instead of
     sampling the volume (get_sdf_volume).  precision "bf16": throughput mode (variants 0/2); "f16x3": split-f16 MFMA at fp32-class accuracy
-    (variants 0 and 2; variant 1 / lat_in fall back to the fp32 kernel).  Returns dict of tensors."""
+    (variants 0 and 2; variant 1 / lat_in fall back to the fp32 kernel).  grid_tables (f16x3, variant 0, lattice mode): (tab_xy, tab_z) from
+    ops.sdf_grid_tables -- layer 0 read from per-axis tables instead of being evaluated per point.  Returns dict of tensors."""
     implicit = precision is None
     precision = config.sdf_precision(precision)
     if implicit and precision == "bf16" and (variant == 1 or want_lat or lat_in is not None):
@@ -372,6 +382,13 @@ def sdf_mlp(blob, vol_cl, pts=None, variant=0, grid_R=0, sign=1.0, index=None, n
     if P == 0 or (n == 0 and n_dev is None):
         return res
     if precision == "f16x3" and variant == 0 and not want_lat and lat_in is None:
+        if grid_tables is not None and pts is None and index is None and n_dev is None:
+            tab_xy, tab_z = grid_tables                  # lattice mode with layer 0 tabulated (weights.sdf_grid_tables + ops.sdf_grid_tables)
+            if tuple(tab_xy.shape) != (int(grid_R) ** 2, 128) or tuple(tab_z.shape) != (int(grid_R), 128):
+                raise ValueError(f"sdf_mlp: grid tables were built for another resolution than {grid_R}")
+            check(_lib.lib().o2345_sdf_grid_x3(_p(blob), _p(vol_cl), D, int(grid_R), float(sign), _p(tab_xy), _p(tab_z), _p(res["sdf"]), _stream()),
+                  "sdf_grid_x3")
+            return res
         check(_lib.lib().o2345_sdf_mlp_x3(_p(blob), _p(vol_cl), D, _p(pts), _p(index, torch.int32), _p(n_dev, torch.int32), n, int(grid_R),
                                           float(sign), _p(res["sdf"]), _stream()), "sdf_mlp_x3")
         return res

@@ -41,8 +41,20 @@ class SceneWeights:
         self.color_mblob = t(weights.pack_color_mfma_blob(self.color_sd))
         self.color_xblob = t(weights.pack_color_x3_blob(self.color_sd))
         self.costreg = CostRegNet(self.costreg_sd, device, precision=color_precision)      # sparse convolutions follow the same mode
+        self._grid_tabs = {}
         self.variance = float(variance)
         self.inv_s = float(np.clip(np.exp(10.0 * variance), 1e-6, 1e6))
+
+    def grid_tables(self, resolution):
+        """Layer 0 of the SDF network tabulated for the extraction lattice of this resolution (built once per resolution; f16x3 mode only)."""
+        if self.sdf_precision != "f16x3":
+            return None
+        R = int(resolution)
+        if R not in self._grid_tabs:
+            axes, bias = weights.sdf_grid_tables(self.sdfW, R)
+            dev = self.sdf_blob.device
+            self._grid_tabs[R] = ops.sdf_grid_tables(torch.from_numpy(axes).to(dev), torch.from_numpy(bias).to(dev))
+        return self._grid_tabs[R]
 
     @classmethod
     def from_state_dicts(cls, device, sdf_network_sd, rendering_network_sd, variance, featurenet_sd=None):
@@ -105,7 +117,7 @@ def render(wt, vol, proj, cam_pos, rays_o, rays_d, near, far, query_cam, n_sampl
 def extract_mesh(wt, vol, proj, cam_pos, resolution, return_index_verts=False):
     """extract_fields + marching cubes + vertex colouring (trainer_generic.py:1309-1363), all on the device."""
     prec = wt.sdf_precision
-    u = ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], None, variant=0, grid_R=resolution, sign=-1.0, precision=prec)["sdf"]
+    u = ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], None, variant=0, grid_R=resolution, sign=-1.0, precision=prec, grid_tables=wt.grid_tables(resolution))["sdf"]
     u = u.view(resolution, resolution, resolution)
     verts_idx, tris = ops.marching_cubes(u, 0.0)
     verts = (verts_idx / (resolution - 1.0) * 2.0 - 1.0)                      # sparse_neus_renderer.py:936

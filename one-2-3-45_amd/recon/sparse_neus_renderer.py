@@ -148,7 +148,8 @@ class SparseNeuSRenderer(nn.Module):
         if not (float(torch.as_tensor(bound_min).min()) == -1.0 and float(torch.as_tensor(bound_max).max()) == 1.0):
             raise NotImplementedError("o2345 extract_fields: bounds (-1, 1) only")
         vol = kwargs["conditional_volume"]
-        u = ops.sdf_mlp(self.sdf_network.sdf_layer.blob(), channel_last(vol), None, variant=0, grid_R=resolution, sign=-1.0)["sdf"]
+        layer = self.sdf_network.sdf_layer
+        u = ops.sdf_mlp(layer.blob(), channel_last(vol), None, variant=0, grid_R=resolution, sign=-1.0, grid_tables=layer.grid_tables(resolution))["sdf"]
         return u.view(resolution, resolution, resolution)
 
     @torch.no_grad()

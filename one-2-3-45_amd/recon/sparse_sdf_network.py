@@ -5,7 +5,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops, weights
+from .. import config, ops, weights
 from ..costreg import CostRegNet
 from ..featurenet import ConvBnReLU
 from ..weights import COSTREG_LAYERS
@@ -60,7 +60,7 @@ class LatentSDFLayer(nn.Module):
                     nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(128))
                     nn.init.constant_(lin.weight[:, -16:], 0.0)
             setattr(self, f"lin{l}", nn.utils.weight_norm(lin))
-        self._blob, self._blob_key = None, None
+        self._blob, self._blob_key, self._W, self._grid_tabs = None, None, None, {}
 
     def blob(self):
         ps = [p for _, p in sorted(self.named_parameters())]
@@ -68,8 +68,19 @@ class LatentSDFLayer(nn.Module):
         if self._blob is None or key != self._blob_key:
             W = weights.sdf_weights_from_state_dict({k: v.detach() for k, v in self.state_dict().items()}, "")
             self._blob = torch.from_numpy(weights.pack_sdf_blob(W)).to(ps[0].device)
-            self._blob_key = key
+            self._blob_key, self._W, self._grid_tabs = key, W, {}
         return self._blob
+
+    def grid_tables(self, resolution):
+        """Layer 0 tabulated for the extraction lattice (csrc/sdf_mlp_x3.hip TAB form; rebuilt when a parameter changes)."""
+        if config.sdf_precision() != "f16x3":
+            return None
+        blob = self.blob()
+        R = int(resolution)
+        if R not in self._grid_tabs:
+            axes, bias = weights.sdf_grid_tables(self._W, R)
+            self._grid_tabs[R] = ops.sdf_grid_tables(torch.from_numpy(axes).to(blob.device), torch.from_numpy(bias).to(blob.device))
+        return self._grid_tabs[R]
 
 
 class _SparseCostRegNet(nn.Module):

@@ -218,6 +218,26 @@ def pack_sparse_conv_x3(K):
     return blob.reshape(-1).view(np.float32).copy()
 
 
+def sdf_grid_tables(W, R):
+    """Layer 0 of the SDF network tabulated per axis for the lattice linspace(-1,1,R)^3 (csrc/sdf_mlp_x3.hip, TAB form): the 39-wide embedding is
+    separable, so W0 . PE(x,y,z) = Tx[ix] + Ty[iy] + Tz[iz] with T_d[i][n] = w0[n,d] p + sum_k w0[n,3+6k+d] sin(2^k p) + w0[n,6+6k+d] cos(2^k p),
+    p = linspace(-1,1,R)[i] as fp32 (the value the kernels use), evaluated in float64 and rounded once.
+    -> (tab_axes float32 [3,R,128], bias float32 [128]), columns in the kernels' lane order [wave half][accumulator block * 16 + register]."""
+    import torch
+    w0 = np.asarray(W["w0"], np.float64)
+    assert w0.shape == (128, 39)
+    p = torch.linspace(-1, 1, int(R), dtype=torch.float32).numpy().astype(np.float64)
+    order = np.array([neuron_of(nb, r, h) for h in (0, 1) for nb in range(4) for r in range(16)])
+    tabs = np.zeros((3, int(R), 128), np.float64)
+    for d in range(3):
+        t = np.outer(p, w0[:, d])
+        for k in range(6):
+            f = float(1 << k)
+            t += np.outer(np.sin(p * f), w0[:, 3 + 6 * k + d]) + np.outer(np.cos(p * f), w0[:, 6 + 6 * k + d])
+        tabs[d] = t[:, order]
+    return tabs.astype(np.float32), np.asarray(W["b0"], np.float32)[order].copy()
+
+
 # ---- colour network blob: keep in sync with csrc/color.hip ---------------------------------------------------------
 def _color_layout():
     segs, off = {}, 0

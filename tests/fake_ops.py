@@ -183,8 +183,12 @@ def abn_forward(self, x, want_nhwc=False):
 
 
 # ------------------------------------------------------------------------------------------------ networks
+def sdf_grid_tables(tab_axes, bias_lane_order):
+    return tab_axes, bias_lane_order
+
+
 def sdf_mlp(blob, vol_cl, pts=None, variant=0, grid_R=0, sign=1.0, index=None, n_dev=None, want_lat=False, out=None, lat_in=None,
-            precision=None):
+            precision=None, grid_tables=None):
     W = _SDF[blob.data_ptr()]
     volume = vol_cl.permute(3, 0, 1, 2)
     if pts is None:
@@ -296,7 +300,7 @@ def install(monkeypatch):
     costreg = importlib.import_module("one-2-3-45_amd.costreg")
     featurenet = importlib.import_module("one-2-3-45_amd.featurenet")
     for name in ("costvol_index", "costvol_gather", "visible_count_list", "costvol_gather_list", "build_index_grid", "scatter_dense", "sdf_mlp",
-                 "pack_color_maps", "color_points", "color_from_features", "render_rays", "marching_cubes", "prune_dilate", "sparse_downsample", "sparse_conv3d", "bn_act_rows", "fpn_level", "pyramid_pack", "conv2d", "conv2d_pack", "conv_x3", "scale_shift_act"):
+                 "pack_color_maps", "color_points", "color_from_features", "render_rays", "marching_cubes", "prune_dilate", "sparse_downsample", "sparse_conv3d", "bn_act_rows", "fpn_level", "pyramid_pack", "conv2d", "conv2d_pack", "conv_x3", "scale_shift_act", "sdf_grid_tables"):
         monkeypatch.setattr(ops, name, globals()[name])
     spnn = importlib.import_module("one-2-3-45_amd.shims.torchsparse.nn")
     monkeypatch.setattr(spnn, "_require_device", lambda t: None)

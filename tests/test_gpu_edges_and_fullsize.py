@@ -189,7 +189,12 @@ def test_fullsize_mesh_properties(full):
     lin = torch.linspace(-1, 1, R).to(dev)            # created on the CPU like extract_fields does (:888-890)
     pts = torch.stack([lin[ii[:, 0]], lin[ii[:, 1]], lin[ii[:, 2]]], -1).contiguous()
     s2 = ops.sdf_mlp(full["wt"].sdf_blob, full["vol"]["vol_cl"], pts, variant=0)["sdf"]
-    assert torch.equal(-s2, u[ii[:, 0], ii[:, 1], ii[:, 2]])            # same kernel, bit-identical coordinates -> bit-identical SDF
+    # the lattice kernel that evaluates the embedding per point: same code, bit-identical coordinates -> bit-identical SDF
+    u_pts = ops.sdf_mlp(full["wt"].sdf_blob, full["vol"]["vol_cl"], None, variant=0, grid_R=R, sign=-1.0).get("sdf").view(R, R, R)
+    assert torch.equal(-s2, u_pts[ii[:, 0], ii[:, 1], ii[:, 2]])
+    # the extraction path reads layer 0 from per-axis tables (fp64-evaluated, csrc/sdf_mlp_x3.hip TAB form): same function to rounding
+    d = (-s2 - u[ii[:, 0], ii[:, 1], ii[:, 2]]).abs()
+    assert float(d.max()) < 2e-5 * max(1.0, float(s2.abs().max())), float(d.max())
     # topology: every vertex is used, every edge is shared by exactly two triangles unless it lies on the grid boundary
     assert int(torch.unique(tris).numel()) == verts.shape[0]
     t = tris.cpu().numpy()

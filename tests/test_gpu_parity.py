@@ -142,6 +142,35 @@ def test_bn_and_abn(dev, ops):
         close(y2, ref.permute(0, 2, 3, 1), what=f"abn nhwc C={C}")
 
 
+@pytest.mark.parametrize("R", [33, 64])
+def test_sdf_lattice_with_tabulated_layer0(dev, ops, R):
+    """extract_fields with layer 0 of the SDF network read from per-axis tables (o2345_sdf_grid_x3) against the oracle and against the kernel that
+    evaluates the embedding per point; the tables themselves against W0 . PE + b0 of the oracle's embedding."""
+    s = small_scene()
+    d = dev_scene(s, dev, ops)
+    W = sdfW_t(s["sdfW"])
+    Wn = pkg.weights
+    axes, bias = Wn.sdf_grid_tables(s["sdfW"], R)
+    lin = torch.linspace(-1, 1, R)
+    order = np.array([Wn.neuron_of(nb, r, h) for h in (0, 1) for nb in range(4) for r in range(16)])
+    rng = np.random.default_rng(R)
+    idx = torch.from_numpy(rng.integers(0, R, (500, 3)))
+    pe = O.embed(torch.stack([lin[idx[:, 0]], lin[idx[:, 1]], lin[idx[:, 2]]], -1), 6).double()
+    ref = (pe @ W["w0"].double().T + W["b0"].double())[:, order]                       # W0 . PE(x, y, z) + b0 in the kernels' lane order
+    got = (torch.from_numpy(axes[0])[idx[:, 0]].double() + torch.from_numpy(axes[1])[idx[:, 1]].double() + torch.from_numpy(axes[2])[idx[:, 2]].double()
+           + torch.from_numpy(bias).double())
+    assert float((got - ref).abs().max()) < 5e-6
+    tabs = ops.sdf_grid_tables(torch.from_numpy(axes).to(dev), torch.from_numpy(bias).to(dev))
+    assert float((tabs[0].view(R, R, 128)[idx[:, 0], idx[:, 1]].cpu().double() + tabs[1][idx[:, 2]].cpu().double() - ref).abs().max()) < 5e-6
+    u_tab = ops.sdf_mlp(d["sdf_blob"], d["vol_cl"], None, variant=0, grid_R=R, sign=-1.0, precision="f16x3", grid_tables=tabs)["sdf"]
+    u_pts = ops.sdf_mlp(d["sdf_blob"], d["vol_cl"], None, variant=0, grid_R=R, sign=-1.0, precision="f16x3")["sdf"]
+    ref = O.sdf_grid(s["dense"][0], W, R)
+    close(u_tab.view(R, R, R), ref, rel=2e-5, what="tabulated lattice vs oracle")
+    close(u_tab, u_pts, rel=2e-5, what="tabulated vs per-point embedding")
+    with pytest.raises(ValueError, match="another resolution"):
+        ops.sdf_mlp(d["sdf_blob"], d["vol_cl"], None, variant=0, grid_R=R + 1, sign=-1.0, precision="f16x3", grid_tables=tabs)
+
+
 @pytest.mark.parametrize("prec", ["f16x3", "fp32"])
 @pytest.mark.parametrize("V", [4, 5])
 def test_color_from_materialised_features(dev, ops, prec, V):
