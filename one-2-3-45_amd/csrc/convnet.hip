@@ -378,7 +378,7 @@ template <int CINP, int K, int STRIDE, int ROWS>
 static void launch_conv_x3(ConvArgs a, int V, int cin, int cout, hipStream_t s) {
     a.nbx = (int)cdiv(a.Wo, 32);
     const int nby = (int)cdiv(a.Ho, 4 * ROWS);
-    a.nblk = a.nbx * nby * V;
+    a.nblk = a.nbx * nby * V;                                                       // <= cdiv(Wo, 32) * cdiv(Ho, 4) * V (workspace bound)
     hipLaunchKernelGGL((k_conv2d_x3<CINP, K, STRIDE, ROWS>), dim3(a.nbx * nby, V), dim3(256), 0, s, a, cin, cout);
     if (a.part)
         hipLaunchKernelGGL(k_conv_stats_finish, dim3(cout), dim3(256), 0, s, a.part, a.nblk, (double)V * a.Ho * a.Wo, cout, a.gamma, a.beta, a.eps, a.abs_gamma, a.out_ss);
@@ -406,7 +406,9 @@ int o2345_conv2d_pack_weights(const float* w_oihw, int cout, int cin, int k, flo
 }
 
 size_t o2345_conv2d_workspace_bytes(int V, int cout, int Ho, int Wo) {
-    return (size_t)cout * cdiv(Wo, CV_TX) * cdiv(Ho, CV_TH) * V * 2 * sizeof(double);      // the one-pixel-per-thread tiling has the most blocks
+    // one (sum, sum of squares) pair of doubles per channel and block; the smallest tile of any kernel here is 32 x 4 output pixels
+    // (k_conv2d_x3 with one row per wave, the stride-2 layers), so this bounds the block count of every variant
+    return (size_t)cout * cdiv(Wo, 32) * cdiv(Ho, 4) * V * 2 * sizeof(double);
 }
 
 // out = conv2d(act(in), w) (+ bias); act = leaky(in * scale + shift) when in_scale_shift is given.  padding = k / 2.
@@ -439,23 +441,24 @@ int o2345_conv2d(const float* in, int V, int cin, int Hi, int Wi, int in_pixel_s
     const long long pix = (long long)V * Ho * Wo;
     const int tier = pix >= 400000 ? 2 : pix >= 100000 ? 1 : 0;
     bool done = false;
-#define O2345_CONV(CI, CO, KK, ST, CC, B4, B2, B1)                                        \
+#define O2345_CONV(CI, CO, KK, ST, CC, PX4, B4, B2, B1)                                   \
     if (!done && cin == CI && cout == CO && k == KK && stride == ST) {                    \
         done = true;                                                                      \
-        if (tier == 2) launch_conv<CI, CO, B4, KK, ST, CC, 4>(a, V, s);                   \
+        if (tier == 2) launch_conv<CI, CO, B4, KK, ST, CC, PX4>(a, V, s);                 \
         else if (tier == 1) launch_conv<CI, CO, B2, KK, ST, CC, 2>(a, V, s);              \
         else launch_conv<CI, CO, B1, KK, ST, CC, 1>(a, V, s);                             \
     }
-    O2345_CONV(3, 8, 3, 1, 3, 8, 8, 8)
-    O2345_CONV(8, 8, 3, 1, 8, 8, 8, 8)
-    O2345_CONV(8, 16, 5, 2, 4, 16, 16, 8)
-    O2345_CONV(16, 16, 3, 1, 8, 16, 16, 8)
-    O2345_CONV(16, 32, 5, 2, 4, 16, 16, 8)
-    O2345_CONV(32, 32, 3, 1, 8, 16, 16, 8)
-    O2345_CONV(32, 32, 1, 1, 32, 16, 16, 8)
-    O2345_CONV(32, 16, 3, 1, 8, 16, 16, 8)
-    O2345_CONV(32, 8, 3, 1, 8, 8, 8, 8)
-    O2345_CONV(56, 16, 3, 1, 8, 16, 16, 8)
+    // (PX4: pixels per thread on the largest maps -- 2 for the 5x5 stride-2 layers, whose 4-pixel input tile would not fit 64 KB of LDS)
+    O2345_CONV(3, 8, 3, 1, 3, 4, 8, 8, 8)
+    O2345_CONV(8, 8, 3, 1, 8, 4, 8, 8, 8)
+    O2345_CONV(8, 16, 5, 2, 4, 2, 16, 16, 8)
+    O2345_CONV(16, 16, 3, 1, 8, 4, 16, 16, 8)
+    O2345_CONV(16, 32, 5, 2, 4, 2, 16, 16, 8)
+    O2345_CONV(32, 32, 3, 1, 8, 4, 16, 16, 8)
+    O2345_CONV(32, 32, 1, 1, 8, 4, 16, 16, 8)
+    O2345_CONV(32, 16, 3, 1, 8, 4, 16, 16, 8)
+    O2345_CONV(32, 8, 3, 1, 8, 4, 8, 8, 8)
+    O2345_CONV(56, 16, 3, 1, 8, 4, 16, 16, 8)
 #undef O2345_CONV
     O2345_REQUIRE(done, "conv2d: no kernel for %d -> %d channels, %dx%d, stride %d (FeatureNet / compress-layer shapes only)", cin, cout, k, k, stride);
     return check_launch("conv2d");

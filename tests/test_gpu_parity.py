@@ -240,6 +240,25 @@ def test_conv2d_vs_torch(dev, ops, cin, cout, k, stride, hw, prec):
         assert torch.equal(y2, y1.permute(0, 2, 3, 1))
 
 
+@pytest.mark.parametrize("cin,cout,k,stride", [(3, 8, 3, 1), (8, 16, 5, 2), (32, 32, 1, 1), (56, 16, 3, 1)])
+@pytest.mark.parametrize("prec", ["f16x3", "fp32"])
+def test_conv2d_large_maps(dev, ops, cin, cout, k, stride, prec):
+    """The launch variants chosen for large maps (2 and 4 pixels per thread in the fp32 form; many tiles and partial-sum blocks in both forms):
+    3 views of 260 x 516 and of 130 x 258 against ATen's fp32 conv2d, incl. the batch statistics."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(cin + cout)
+    for hw in ((260, 516), (130, 258)):
+        x = torch.from_numpy(rng.normal(0.1, 1.0, (3, cin) + hw).astype(np.float32))
+        w = torch.from_numpy((rng.normal(0, 1.0, (cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32))
+        gamma = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)); beta = torch.from_numpy(rng.normal(0, 0.2, cout).astype(np.float32))
+        y, ss = ops.conv2d(x.to(dev), w.to(dev), None, stride, bn=(gamma.to(dev), beta.to(dev), 1e-5, True), precision=prec)
+        ref = F.conv2d(x, w, None, stride, k // 2)
+        close(y, ref, rel=1e-5, what=f"conv2d {hw}")
+        rd = ref.double()
+        scale = (gamma.double().abs() + 1e-5) / torch.sqrt(rd.var((0, 2, 3), unbiased=False) + 1e-5)
+        close(ss[:cout], scale.float(), rel=2e-5, what="scale"); close(ss[cout:], (beta.double() - rd.mean((0, 2, 3)) * scale).float(), rel=2e-5, what="shift")
+
+
 @pytest.mark.parametrize("prec", ["f16x3", "fp32"])
 def test_conv2d_channel_last_input(dev, ops, prec):
     """The compress layer reading its 56 input channels out of the channel-last colour map [V,H,W,64] (offset 3) == the same convolution on the
