@@ -59,8 +59,8 @@ int o2345_pyramid_pack(const float* f2, const float* s1, const float* s0, const 
  *   nn.Conv2d weight [cout,cin,k,k]).  in_scale_shift [2*cin] (may be NULL): the InPlaceABN of the PRODUCER of `in` is applied while `in` is read,
  *   act(x) = leaky_relu(x * scale + shift, slope) -- the activated tensor is never stored.  out_scale_shift [2*cout] (may be NULL): batch
  *   statistics of `out` over (V,Ho,Wo) -> this layer's own (scale, shift) = ((|gamma| + eps) / sqrt(var + eps), beta - mean * scale) for the
- *   consumer to apply (needs gamma, beta and a workspace of conv2d_workspace_bytes).  Shapes: the ten (cin, cout, k, stride) of FeatureNet and
- *   the compress layer; anything else is an error.
+ *   consumer to apply (needs gamma, beta and a workspace of conv2d_workspace_bytes).  Shapes (fp32 form): the (cin, cout, k, stride) combinations of FeatureNet
+ *   and the compress layer (16 or 8 outputs); anything else is an error.  The matrix-core form takes any cin <= 64, cout <= 32 with those (k, stride).
  * fpn_level_act: fpn_level whose `fine` input is a raw convolution output with its (scale, shift) applied on load.
  * scale_shift_act: y = leaky_relu(x * scale + shift) for x [V,C,H,W], written as NCHW and / or channel-last NHWC (C = 8, 16, 32). */
 int o2345_conv2d_pack_weights(const float* w_oihw, int cout, int cin, int k, float* packed, void* stream);

@@ -459,6 +459,7 @@ int o2345_conv2d(const float* in, int V, int cin, int Hi, int Wi, int in_pixel_s
     O2345_CONV(32, 16, 3, 1, 8, 4, 16, 16, 8)
     O2345_CONV(32, 8, 3, 1, 8, 4, 8, 8, 8)
     O2345_CONV(56, 16, 3, 1, 8, 4, 16, 16, 8)
+    O2345_CONV(56, 8, 3, 1, 8, 4, 8, 8, 8)               // a compress layer with d_pyramid_feature_compress = 8
 #undef O2345_CONV
     O2345_REQUIRE(done, "conv2d: no kernel for %d -> %d channels, %dx%d, stride %d (FeatureNet / compress-layer shapes only)", cin, cout, k, k, stride);
     return check_launch("conv2d");

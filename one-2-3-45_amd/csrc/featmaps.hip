@@ -103,13 +103,16 @@ __global__ __launch_bounds__(256) void k_pyramid_pack(const float* __restrict__ 
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
         for (int c = 0; c < 32; ++c) tr[wave][lane][c] = px[32 * half + c];
-        // (one wave writes and reads its own tile: no workgroup barrier needed, the LDS operations of a wave complete in order)
+        // one wave writes and reads its own tile: no workgroup barrier needed (the LDS operations of a wave complete in order); the wave barriers
+        // only keep the compiler from moving the cross-lane reads above the writes / the next half's writes above the reads
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int pp = q * 8 + (lane >> 3), c4 = (lane & 7) * 4;
             const float4 t = make_float4(tr[wave][pp][c4], tr[wave][pp][c4 + 1], tr[wave][pp][c4 + 2], tr[wave][pp][c4 + 3]);
             if (p0 + pp < HW) *reinterpret_cast<float4*>(dst + (size_t)pp * 64 + 32 * half + c4) = t;
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

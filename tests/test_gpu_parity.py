@@ -200,7 +200,7 @@ def test_color_from_materialised_features(dev, ops, prec, V):
 
 
 CONV_SHAPES = [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1), (16, 32, 5, 2), (32, 32, 3, 1), (32, 32, 1, 1), (32, 16, 3, 1), (32, 8, 3, 1),
-               (56, 16, 3, 1)]
+               (56, 16, 3, 1), (56, 8, 3, 1)]
 
 
 @pytest.mark.parametrize("cin,cout,k,stride", CONV_SHAPES)
