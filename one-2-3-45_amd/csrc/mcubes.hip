@@ -33,8 +33,19 @@ static McGrid mc_grid(int n0, int n1, int n2, double iso) {
     return McGrid{n0, n1, n2, (long long)n1 * n2, (long long)n2, (long long)n0 * n1 * n2, f, iso};
 }
 
-__device__ __forceinline__ void mc_point_counts(const float* __restrict__ u, const McGrid& g, long long p, int& nv, int& nt) {
-    const int z = (int)(p % g.n2), y = (int)((p / g.n2) % g.n1), x = (int)(p / g.s0);
+// grid point p -> (x, y, z); 32-bit divisions whenever the volume has fewer than 2^32 points (a 64-bit division costs ~200 instructions)
+__device__ __forceinline__ void mc_decompose(const McGrid& g, long long p, int& x, int& y, int& z) {
+    if (g.n <= 0xFFFFFFFFll) {
+        const unsigned up = (unsigned)p, q = up / (unsigned)g.n2;
+        z = (int)(up - q * (unsigned)g.n2);
+        x = (int)(q / (unsigned)g.n1);
+        y = (int)(q - (unsigned)x * (unsigned)g.n1);
+    } else {
+        z = (int)(p % g.n2); y = (int)((p / g.n2) % g.n1); x = (int)(p / g.s0);
+    }
+}
+
+__device__ __forceinline__ void mc_point_counts(const float* __restrict__ u, const McGrid& g, long long p, int x, int y, int z, int& nv, int& nt) {
     const bool in0 = u[p] <= g.iso;
     nv = 0;
     if (x > 0) nv += (in0 != (u[p - g.s0] <= g.iso));
@@ -77,14 +88,17 @@ __device__ __forceinline__ int block_scan_excl(int v, int* lds /*[5]*/, int& tot
 __global__ __launch_bounds__(256) void k_mc_count(const float* __restrict__ u, McGrid g, uint8_t* __restrict__ vcnt,
                                                   uint16_t* __restrict__ tcase, int* __restrict__ vblock, int* __restrict__ tblock) {
     __shared__ int lds[5];
-    const long long p0 = (long long)blockIdx.x * MC_TILE + (long long)threadIdx.x * MC_ITEMS;
+    // item i of thread t is grid point tile + i * 256 + t: the lanes of a wave read consecutive floats (the counts only need the tile's totals,
+    // so the order inside the tile is free here; k_mc_offsets scans the stored per-point counts in grid order)
+    const long long p0 = (long long)blockIdx.x * MC_TILE + threadIdx.x;
     int sv = 0, st = 0;
 #pragma unroll
     for (int i = 0; i < MC_ITEMS; ++i) {
-        const long long p = p0 + i;
+        const long long p = p0 + i * 256;
         if (p < g.n) {
-            int nv, nt;
-            mc_point_counts(u, g, p, nv, nt);
+            int x, y, z, nv, nt;
+            mc_decompose(g, p, x, y, z);
+            mc_point_counts(u, g, p, x, y, z, nv, nt);
             vcnt[p] = (uint8_t)nv;
             tcase[p] = (uint16_t)nt;          // low byte: triangle count, high byte: cube index
             sv += nv; st += (nt & 0xff);
@@ -144,7 +158,9 @@ __global__ __launch_bounds__(256) void k_mc_verts(const float* __restrict__ u, M
                                                   const int* __restrict__ vbase, double* __restrict__ verts) {
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= g.n || vcnt[p] == 0) return;
-    const int c[3] = {(int)(p / g.s0), (int)((p / g.n2) % g.n1), (int)(p % g.n2)};
+    int cx, cy, cz;
+    mc_decompose(g, p, cx, cy, cz);
+    const int c[3] = {cx, cy, cz};
     const long long back[3] = {g.s0, g.s1, 1};
     const double f1 = (double)u[p], iso = g.iso_d;
     long long id = vbase[p];
@@ -161,9 +177,8 @@ __global__ __launch_bounds__(256) void k_mc_verts(const float* __restrict__ u, M
 }
 
 __device__ __forceinline__ int mc_vertex_id(const float* __restrict__ u, const McGrid& g, const int* __restrict__ vbase,
-                                            long long q, int axis) {
-    // rank of slot `axis` among the present slots of grid point q
-    const int z = (int)(q % g.n2), y = (int)((q / g.n2) % g.n1), x = (int)(q / g.s0);
+                                            long long q, int x, int y, int axis) {
+    // rank of slot `axis` among the present slots of grid point q = (x, y, .)
     const bool in0 = u[q] <= g.iso;
     int id = vbase[q];
     if (axis > 0 && x > 0) id += (in0 != (u[q - g.s0] <= g.iso));
@@ -180,12 +195,14 @@ __global__ __launch_bounds__(256) void k_mc_tris(const float* __restrict__ u, Mc
     const int nt = tc & 0xff, ci = tc >> 8;
     if (!nt) return;
     long long t0 = tbase[p];
+    int x, y, z;
+    mc_decompose(g, p, x, y, z);
     for (int t = 0; t < nt; ++t) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int e = MC_TRI[ci][3 * t + q];
             const long long gq = p + MC_FAR[e][0] * g.s0 + MC_FAR[e][1] * g.s1 + MC_FAR[e][2];
-            tris[3 * (t0 + t) + q] = (IDX)mc_vertex_id(u, g, vbase, gq, MC_AXIS[e]);
+            tris[3 * (t0 + t) + q] = (IDX)mc_vertex_id(u, g, vbase, gq, x + MC_FAR[e][0], y + MC_FAR[e][1], MC_AXIS[e]);
         }
     }
 }
