@@ -202,11 +202,11 @@ __global__ __launch_bounds__(256) void k_ss_apply(const float* __restrict__ x /*
 // The same convolution as an implicit GEMM  D[co][pixel] = sum over (tap, ci) W[co][ci][tap] * act(in)[ci][pixel + tap]  on
 // v_mfma_f32_32x32x16_f16 in the split-f16 form of csrc/sparse_mfma.hip (hi*hi + hi*lo + lo*hi, fp32 accumulate, fp32-class accuracy).
 // A wave owns ROWS row segments of 32 output pixels (B column = lane & 31) and all <= 32 output channels; a k step is (tap, 16-channel group):
-// the two wave halves supply 8 input channels each.  A workgroup (4 waves, 32 x 4*ROWS output pixels) stages one 16-channel group of its input
-// tile at a time: activation (the producer's ABN, on load) and the f16 split happen ONCE per staged value, the halves go to LDS as 16-byte
-// items [hi|lo][channel octet][pixel] so that a B operand is one conflict-free ds_read_b128; the next group's raw values are already in flight
-// while the current group's MFMAs run.  The A operands (weights, [tap][group][hi|lo][64 lanes][8 f16], packed by k_conv_pack_x3) stream from
-// L2 through a buffer descriptor one tap ahead -- 2 KB per step, identical for every wave of the grid.
+// the two wave halves supply 8 input channels each.  A workgroup (4 waves, 32 x 4*ROWS output pixels) stages its whole input tile once, all
+// channels: activation (the producer's ABN, on load) and the f16 split happen ONCE per staged value, the halves go to LDS as 16-byte items
+// [hi|lo][channel octet][pixel] so that a B operand is one conflict-free ds_read_b128; one barrier, then the wave runs its K*K*CINP/16 steps.
+// The A operands (weights, [tap][group][hi|lo][64 lanes][8 f16], packed by k_conv_pack_x3) stream from L2 through a buffer descriptor a few
+// steps ahead -- 2 KB per step, identical for every wave of the grid.
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
@@ -224,7 +224,148 @@ __device__ __forceinline__ AOpX conv_a_fetch(__amdgpu_buffer_rsrc_t rs, int step
 template <int CINP, int K, int STRIDE, int ROWS>
 __global__ __launch_bounds__(256) void k_conv2d_x3(ConvArgs a, int cin, int cout) {
     constexpr int NU = CINP / 16, TH = 4 * ROWS, PAD = K / 2, IW = 31 * STRIDE + K, IH = (TH - 1) * STRIDE + K, NPIX = IH * IW;
-    constexpr int NLD = (NPIX + 255) / 256;                                      // tile pixels per thread; a thread stages all 16 channels of its pixels
+    constexpr int NLD = (NPIX + 255) / 256;                                      // tile pixels per thread; a thread stages ALL channels of its pixels
+    __shared__ float4 plane[2][2 * NU][NPIX];                                     // [hi | lo][channel octet][pixel]: a B operand is one 16-byte item
+    static_assert(sizeof(plane) >= 4 * 32 * 2 * sizeof(double), "the statistics scratch reuses the tile memory");
+    double (*red)[32][2] = reinterpret_cast<double (*)[32][2]>(&plane[0][0][0]);  // [wave][channel][sum | sum of squares], after the MFMAs
+    __shared__ float ssl[2][CINP];                                                // the producer's (scale | shift): read per staged value, kept in LDS
+    if (a.in_ss && threadIdx.x < 2 * CINP) {
+        const int k = threadIdx.x / CINP, c = threadIdx.x % CINP;
+        ssl[k][c] = c < cin ? a.in_ss[k * cin + c] : 0.f;
+    }
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    const int bx = blockIdx.x % a.nbx, by = blockIdx.x / a.nbx, v = blockIdx.y;
+    const int ox = bx * 32 + j, oy0 = by * TH + wave * ROWS;
+    const int gx0 = bx * 32 * STRIDE - PAD, gy0 = by * TH * STRIDE - PAD;
+    const float* src = a.in + (size_t)v * a.view_stride;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, K * K * NU * 2048, 0x00020000);
+    float m1 = -1.f;
+    asm volatile("" : "+v"(m1));                                                 // keeps fma(hi, -1, x) a v_fma_mix_f32 (see sdf_mlp_x3.hip)
+    // ---- stage the whole input tile, all channel groups at once: ONE global round trip per tile (staging group by group exposed one HBM latency
+    //      per group and two barriers -- the matrix pipe was busy 23 % of the time); loads are unconditional (clamped pixel / channel), what lies
+    //      outside the image or beyond cin is zeroed after the activation (zero padding applies to the ACTIVATED input)
+    {
+        unsigned pix_src[NLD];                                                    // element offsets from `src` (a view has < 2^32 elements)
+        bool pix_in[NLD];
+#pragma unroll
+        for (int jj = 0; jj < NLD; ++jj) {
+            const int r = min((int)threadIdx.x + 256 * jj, NPIX - 1), iy = r / IW, ix = r % IW;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            pix_in[jj] = gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi;
+            pix_src[jj] = (unsigned)(min(max(gy, 0), a.Hi - 1) * a.Wi + min(max(gx, 0), a.Wi - 1)) * (unsigned)a.pix_stride;
+        }
+        float pre[NLD][CINP];
+#pragma unroll
+        for (int jj = 0; jj < NLD; ++jj)
+#pragma unroll
+            for (int c = 0; c < CINP; ++c) pre[jj][c] = (src + (size_t)min(c, cin - 1) * a.chan_stride)[pix_src[jj]];     // wave-uniform channel plane
+        __syncthreads();                                                         // ssl is in place
+#pragma unroll
+        for (int jj = 0; jj < NLD; ++jj) {
+            const int r = threadIdx.x + 256 * jj;
+            if (r < NPIX) {
+#pragma unroll
+                for (int oct = 0; oct < 2 * NU; ++oct) {
+                    float x[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int c = 8 * oct + t;
+                        float val = pre[jj][c];
+                        if (a.in_ss) {
+                            val = val * ssl[0][c] + ssl[1][c];
+                            val = fmaxf(val, val * a.slope);                     // leaky ReLU, 0 <= slope < 1
+                        }
+                        x[t] = (pix_in[jj] && c < cin) ? val : 0.f;
+                    }
+                    union { h16x8 v8; h16x2 v2[4]; hh16x2 w2[4]; float4 f4; } bh, bl;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bh.v2[q] = __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]);
+                        bl.v2[q] = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)bh.w2[q][0], m1, x[2 * q]), __builtin_fmaf((float)bh.w2[q][1], m1, x[2 * q + 1]));
+                    }
+                    plane[0][oct][r] = bh.f4;
+                    plane[1][oct][r] = bl.f4;
+                }
+            }
+        }
+    }
+    // ---- k steps (tap, channel group) in the order of the operand records; the A operands stream from L2 PD steps ahead (nothing else is in
+    //      flight on the vector-memory counter, so a wait for one record waits for nothing else)
+    constexpr int NS = K * K * NU, PD = NS < 4 ? NS : 4;
+    AOpX abuf[PD];
+#pragma unroll
+    for (int st = 0; st < PD; ++st) abuf[st] = conv_a_fetch(rs, st, lane);
+    f32x16 acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[r][q] = 0.f;
+    __syncthreads();                                                             // the tile is staged
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        const AOpX A = abuf[st % PD];
+        if (st + PD < NS) abuf[st % PD] = conv_a_fetch(rs, st + PD, lane);
+        const int tap = st / NU, u = st % NU, ky = tap / K, kx = tap % K;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int pix = ((wave * ROWS + r) * STRIDE + ky) * IW + j * STRIDE + kx;
+            const h16x8 bh = __builtin_bit_cast(h16x8, plane[0][2 * u + h][pix]), bl = __builtin_bit_cast(h16x8, plane[1][2 * u + h][pix]);
+            acc[r] = MFMA_F16(A.lo, bh, acc[r]);
+            acc[r] = MFMA_F16(A.hi, bl, acc[r]);
+            acc[r] = MFMA_F16(A.hi, bh, acc[r]);
+        }
+    }
+    // register 4g + i of a lane holds output channel 8g + 4h + i of pixel column j
+    float s[16], q2[16], bv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { s[q] = 0.f; q2[q] = 0.f; bv[q] = 0.f; }
+    if (a.bias) {                                                                // all 16 loads in flight together (clamped index: no branch per value)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bv[q] = a.bias[min(8 * (q >> 2) + 4 * h + (q & 3), cout - 1)];
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int oy = oy0 + r;
+        const bool live = oy < a.Ho && ox < a.Wo;
+        float* dst = a.out + ((size_t)v * cout * a.Ho + (live ? oy : 0)) * a.Wo + (live ? ox : 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = 8 * (q >> 2) + 4 * h + (q & 3);
+            const float val = acc[r][q] + bv[q];
+            if (live && co < cout) {
+                dst[(size_t)co * a.Ho * a.Wo] = val;
+                s[q] += val; q2[q] = fmaf(val, val, q2[q]);
+            }
+        }
+    }
+    if (!a.part) return;
+    __syncthreads();                                                             // every wave is done with the tile: its memory becomes `red`
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+#pragma unroll
+        for (int off = 16; off; off >>= 1) { s[q] += __shfl_xor(s[q], off); q2[q] += __shfl_xor(q2[q], off); }
+        if (j == 0) { const int co = 8 * (q >> 2) + 4 * h + (q & 3); red[wave][co][0] = (double)s[q]; red[wave][co][1] = (double)q2[q]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * cout) {
+        const int co = threadIdx.x >> 1, k = threadIdx.x & 1;
+        const double t = (red[0][co][k] + red[1][co][k]) + (red[2][co][k] + red[3][co][k]);
+        a.part[((size_t)co * a.nblk + (size_t)v * gridDim.x + blockIdx.x) * 2 + k] = t;
+    }
+}
+
+// The same kernel with the input tile staged one 16-channel group at a time (two barriers and one global round trip per group, the next group's
+// raw values in flight during the current group's MFMAs): for 64 input channels the whole tile (87 KB with two rows per wave) would leave one
+// workgroup per CU, and one row per wave costs more in halo loads than the single round trip saves (measured on the compress layer: 181 us with
+// the whole tile staged at once and one row per wave, 110 us staged by groups).
+template <int CINP, int K, int STRIDE, int ROWS, bool CL>
+__global__ __launch_bounds__(256) void k_conv2d_x3_staged(ConvArgs a, int cin, int cout) {
+    constexpr int NU = CINP / 16, TH = 4 * ROWS, PAD = K / 2, IW = 31 * STRIDE + K, IH = (TH - 1) * STRIDE + K, NPIX = IH * IW;
+    // staging work of a thread per 16-channel group.  Channel-first source: NLD tile pixels, all 16 channels of each (consecutive lanes = consecutive
+    // pixels of one channel plane: coalesced).  Channel-LAST source (CL, chan_stride = 1): one channel (lane & 15) of NLD tile pixels, 16 pixels per
+    // pass of the workgroup -- consecutive lanes read consecutive channels, a wave load covers 4 pixels x 64 contiguous bytes instead of 64 pixels
+    // 256 bytes apart (measured on the compress layer reading the [V,H,W,64] colour map: 168 -> 118 us per call at 8 views, 615 -> 412 us at 32)
+    constexpr int NLD = CL ? (NPIX + 15) / 16 : (NPIX + 255) / 256;
     __shared__ float4 plane[2][2][NPIX];                                          // [hi | lo][channel octet][pixel]: a B operand is one 16-byte item
     __shared__ double red[4][32][2];
     __shared__ float ssl[2][CINP];                                                // the producer's (scale | shift): read per staged value, kept in LDS
@@ -246,26 +387,54 @@ __global__ __launch_bounds__(256) void k_conv2d_x3(ConvArgs a, int cin, int cout
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[r][q] = 0.f;
     // the pixels this thread stages: clamped source address (loads are unconditional), in-image flag (zero padding applies to the ACTIVATED input)
-    const float* pix_src[NLD];
+    unsigned pix_src[NLD];                                                        // element offsets from `src` (a view has < 2^32 elements)
     bool pix_in[NLD];
+    const int my_c = threadIdx.x & 15;                                            // CL: this thread's channel inside a group
 #pragma unroll
     for (int jj = 0; jj < NLD; ++jj) {
-        const int r = min((int)threadIdx.x + 256 * jj, NPIX - 1), iy = r / IW, ix = r % IW;
+        const int r = min(CL ? (int)(threadIdx.x >> 4) + 16 * jj : (int)threadIdx.x + 256 * jj, NPIX - 1), iy = r / IW, ix = r % IW;
         const int gy = gy0 + iy, gx = gx0 + ix;
         pix_in[jj] = gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi;
-        pix_src[jj] = src + ((size_t)min(max(gy, 0), a.Hi - 1) * a.Wi + min(max(gx, 0), a.Wi - 1)) * a.pix_stride;
+        pix_src[jj] = (unsigned)(min(max(gy, 0), a.Hi - 1) * a.Wi + min(max(gx, 0), a.Wi - 1)) * (unsigned)a.pix_stride;
     }
-    float pre[NLD][16];
-    auto fetch = [&](int u) {                                                     // channel numbers are wave-uniform: scalar offsets
+    float pre[NLD][CL ? 1 : 16];
+    auto fetch = [&](int u) {
 #pragma unroll
-        for (int jj = 0; jj < NLD; ++jj)
+        for (int jj = 0; jj < NLD; ++jj) {
+            if constexpr (CL) pre[jj][0] = src[pix_src[jj] + (unsigned)min(16 * u + my_c, cin - 1)];
+            else {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) pre[jj][t] = pix_src[jj][(size_t)min(16 * u + t, cin - 1) * a.chan_stride];
+                for (int t = 0; t < 16; ++t) pre[jj][t] = (src + (size_t)min(16 * u + t, cin - 1) * a.chan_stride)[pix_src[jj]];   // wave-uniform channel plane
+            }
+        }
     };
     fetch(0);
 #pragma unroll 1
     for (int u = 0; u < NU; ++u) {
         __syncthreads();                                                         // the previous group's MFMAs have read their operands
+        if constexpr (CL) {
+            const int c = 16 * u + my_c;
+            const float sc = a.in_ss ? ssl[0][c] : 1.f, sh = a.in_ss ? ssl[1][c] : 0.f;
+            _Float16* const ph = reinterpret_cast<_Float16*>(&plane[0][my_c >> 3][0]) + (my_c & 7);
+            _Float16* const pl = reinterpret_cast<_Float16*>(&plane[1][my_c >> 3][0]) + (my_c & 7);
+#pragma unroll
+            for (int jj = 0; jj < NLD; ++jj) {
+                const int r = (int)(threadIdx.x >> 4) + 16 * jj;
+                if (r < NPIX) {
+                    float val = pre[jj][0];
+                    if (a.in_ss) {
+                        val = val * sc + sh;
+                        val = fmaxf(val, val * a.slope);
+                    }
+                    val = (pix_in[jj] && c < cin) ? val : 0.f;
+                    union { h16x2 v2; hh16x2 w2; } bh, bl;
+                    bh.v2 = __builtin_amdgcn_cvt_pkrtz(val, 0.f);
+                    bl.v2 = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)bh.w2[0], m1, val), 0.f);
+                    ph[8 * r] = bh.w2[0];
+                    pl[8 * r] = bl.w2[0];
+                }
+            }
+        } else {
 #pragma unroll
         for (int jj = 0; jj < NLD; ++jj) {
             const int r = threadIdx.x + 256 * jj;
@@ -293,6 +462,7 @@ __global__ __launch_bounds__(256) void k_conv2d_x3(ConvArgs a, int cin, int cout
                     plane[1][oct][r] = bl.f4;
                 }
             }
+        }
         }
         __syncthreads();
         // A operands of the first taps, THEN the next group's raw values, then the MFMAs: the vector-memory counter retires in order, so a wait for
@@ -374,12 +544,16 @@ __global__ void k_conv_pack_x3(const float* __restrict__ w, int cout, int cin, i
     out[(size_t)step * 1024 + 512 + lane * 8 + t] = lo;
 }
 
-template <int CINP, int K, int STRIDE, int ROWS>
+template <int CINP, int K, int STRIDE, int ROWS, bool STAGED = false>
 static void launch_conv_x3(ConvArgs a, int V, int cin, int cout, hipStream_t s) {
     a.nbx = (int)cdiv(a.Wo, 32);
     const int nby = (int)cdiv(a.Ho, 4 * ROWS);
     a.nblk = a.nbx * nby * V;                                                       // <= cdiv(Wo, 32) * cdiv(Ho, 4) * V (workspace bound)
-    hipLaunchKernelGGL((k_conv2d_x3<CINP, K, STRIDE, ROWS>), dim3(a.nbx * nby, V), dim3(256), 0, s, a, cin, cout);
+    if constexpr (STAGED) {
+        if (a.chan_stride == 1) hipLaunchKernelGGL((k_conv2d_x3_staged<CINP, K, STRIDE, ROWS, true>), dim3(a.nbx * nby, V), dim3(256), 0, s, a, cin, cout);
+        else hipLaunchKernelGGL((k_conv2d_x3_staged<CINP, K, STRIDE, ROWS, false>), dim3(a.nbx * nby, V), dim3(256), 0, s, a, cin, cout);
+    }
+    else hipLaunchKernelGGL((k_conv2d_x3<CINP, K, STRIDE, ROWS>), dim3(a.nbx * nby, V), dim3(256), 0, s, a, cin, cout);
     if (a.part)
         hipLaunchKernelGGL(k_conv_stats_finish, dim3(cout), dim3(256), 0, s, a.part, a.nblk, (double)V * a.Ho * a.Wo, cout, a.gamma, a.beta, a.eps, a.abs_gamma, a.out_ss);
 }
@@ -481,6 +655,7 @@ int o2345_conv2d_x3(const float* in, int V, int cin, int Hi, int Wi, int in_pixe
     O2345_REQUIRE(in && w_packed_x3 && out && V >= 1 && Hi >= 1 && Wi >= 1, "conv2d_x3: bad arguments");
     O2345_REQUIRE(in_pixel_stride <= 0 || (in_channel_offset >= 0 && in_channel_offset + cin <= in_pixel_stride), "conv2d_x3: channel-last input: offset + cin must fit the pixel stride");
     O2345_REQUIRE(cout >= 1 && cout <= 32 && cin >= 1 && cin <= 64, "conv2d_x3: at most 64 input and 32 output channels (got %d -> %d)", cin, cout);
+    O2345_REQUIRE((long long)Hi * Wi * (in_pixel_stride > 0 ? in_pixel_stride : 1) < (1ll << 31), "conv2d_x3: a view must have fewer than 2^31 elements per channel plane");
     const int pad = k / 2;
     const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
     const bool stats = out_scale_shift != nullptr;
@@ -498,7 +673,7 @@ int o2345_conv2d_x3(const float* in, int V, int cin, int Hi, int Wi, int in_pixe
     // bound by the latency of their loads, occupancy matters more than operand reuse
     if (k == 3 && stride == 1 && cinp == 16) launch_conv_x3<16, 3, 1, 2>(a, V, cin, cout, s);
     else if (k == 3 && stride == 1 && cinp == 32) launch_conv_x3<32, 3, 1, 2>(a, V, cin, cout, s);
-    else if (k == 3 && stride == 1 && cinp == 64) launch_conv_x3<64, 3, 1, 2>(a, V, cin, cout, s);
+    else if (k == 3 && stride == 1 && cinp == 64) launch_conv_x3<64, 3, 1, 2, true>(a, V, cin, cout, s);        // staged by channel groups (see above)
     else if (k == 5 && stride == 2 && cinp == 16) launch_conv_x3<16, 5, 2, 1>(a, V, cin, cout, s);
     else if (k == 1 && stride == 1 && cinp == 32) launch_conv_x3<32, 1, 1, 2>(a, V, cin, cout, s);
     else done = false;
