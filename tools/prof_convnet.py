@@ -12,7 +12,7 @@ inp = bench.make_inputs(dev, int(os.environ.get("VIEWS", "8")), 0, 2)
 x = inp["imgs"].contiguous().float()
 with torch.no_grad():
     for _ in range(3):
-        fm, cm = fn.fused_pyramid(wt.featurenet, x, want_cmaps=True)
-        f = wt.compress.forward_nhwc(fm)
+        _, cm = fn.fused_pyramid(wt.featurenet, x, want_cmaps=True, want_nchw=False)      # the pipeline's path: channel-last map only
+        f = wt.compress.forward_nhwc(cm, nhwc_offset=3)
 torch.cuda.synchronize()
 print("ok", tuple(f.shape))

@@ -20,11 +20,10 @@ def timed(fn_, reps=5):
     return min(ts), r
 imgs, aff, origin = inp["imgs"], inp["aff"], inp["origin"]
 with torch.no_grad():
-    t, fmaps = timed(lambda: fn.fused_pyramid(wt.featurenet, imgs).contiguous()); print(f"featurenet + pyramid  {t:.3f} ms")
-    t, feats = timed(lambda: wt.compress.forward_nhwc(fmaps)); print(f"compress conv + ABN   {t:.3f} ms")
+    t, (_, cmaps_) = timed(lambda: fn.fused_pyramid(wt.featurenet, imgs, want_cmaps=True, want_nchw=False)); print(f"featurenet + pyramid  {t:.3f} ms")
+    t, feats = timed(lambda: wt.compress.forward_nhwc(cmaps_, nhwc_offset=3)); print(f"compress conv + ABN   {t:.3f} ms")
     t, (cnt, row, coords, n) = timed(lambda: ops.costvol_index(aff, V, 256, 256, (D, D, D), vs, origin)); print(f"costvol index         {t:.3f} ms  ({int(n)} voxels)")
     t, rows = timed(lambda: ops.costvol_gather(feats, aff, (D, D, D), vs, origin, cnt, coords)); print(f"costvol gather        {t:.3f} ms")
     t, rows16 = timed(lambda: wt.costreg.forward(rows, coords, row, (D, D, D))); print(f"sparse CNN            {t:.3f} ms")
     t, _ = timed(lambda: ops.scatter_dense(rows16, row, (D, D, D), want_cf=False)); print(f"scatter dense         {t:.3f} ms")
-    t, _ = timed(lambda: ops.pack_color_maps(fmaps, imgs.contiguous())); print(f"pack colour maps      {t:.3f} ms")
     t, _ = timed(lambda: pipeline.build_volume(wt, imgs, aff, origin, D, vs)); print(f"build_volume total    {t:.3f} ms")
