@@ -274,6 +274,11 @@ def test_conv2d_channel_last_input(dev, ops, prec):
     assert torch.equal(y0, y1) and torch.equal(ss0, ss1)
     with pytest.raises(ValueError, match="do not fit"):
         ops.conv2d(cm, w, precision=prec, nhwc_offset=9)
+    # a 32-channel layer reading channels 5..37 of the same map (the whole-tile kernel's channel-last addressing)
+    w32 = torch.from_numpy((rng.normal(0, 1, (16, 32, 3, 3)) / 17).astype(np.float32)).to(dev)
+    y2, _ = ops.conv2d(cm[..., 5:37].permute(0, 3, 1, 2).contiguous(), w32, precision=prec)
+    y3, _ = ops.conv2d(cm, w32, precision=prec, nhwc_offset=5)
+    assert torch.equal(y2, y3)
     # k_pyramid_pack: channel-last map alone (no channel-first tensor) == the map written together with it
     f2 = torch.from_numpy(rng.normal(0, 1, (V, 32, H // 4, W // 4)).astype(np.float32)).to(dev)
     s1 = torch.from_numpy(rng.normal(0, 1, (V, 16, H // 2, W // 2)).astype(np.float32)).to(dev)
