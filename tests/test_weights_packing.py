@@ -172,3 +172,21 @@ def test_shared_rows_matrix_operand_of_color_pts(pkg):
     assert np.abs(rec - A).max() <= 2.0 ** -21 * max(1.0, np.abs(A).max())
     # the prefix read by k_color_mfma is unchanged by the appended segment
     assert off == W.CM_LAYOUT["S_SCALAR"][0] + 4 and W.CX_A_S == W.CX_A_END + (off - W.CM_TAIL0)
+
+
+def test_sdf_grid_tables_are_the_separable_first_layer(pkg):
+    """weights.sdf_grid_tables (the TAB form of csrc/sdf_mlp_x3.hip): on the lattice linspace(-1,1,R)^3 the first layer of the SDF network is
+    b0 + Tx[ix] + Ty[iy] + Tz[iz]; checked against W0 . embed(p) + b0 of the oracle's embedding, columns in the kernels' lane order."""
+    W = _weights(pkg)
+    for R in (17, 64):
+        axes, bias = pkg.weights.sdf_grid_tables(W, R)
+        assert axes.shape == (3, R, 128) and axes.dtype == np.float32 and bias.shape == (128,)
+        order = np.array([pkg.weights.neuron_of(nb, r, h) for h in (0, 1) for nb in range(4) for r in range(16)])
+        assert sorted(order.tolist()) == list(range(128))
+        lin = torch.linspace(-1, 1, R)
+        rng = np.random.default_rng(R)
+        idx = rng.integers(0, R, (300, 3))
+        p = torch.stack([lin[idx[:, 0]], lin[idx[:, 1]], lin[idx[:, 2]]], -1)
+        ref = (O.embed(p).double() @ torch.from_numpy(W["w0"]).double().T + torch.from_numpy(W["b0"]).double()).numpy()[:, order]
+        got = axes[0][idx[:, 0]].astype(np.float64) + axes[1][idx[:, 1]] + axes[2][idx[:, 2]] + bias
+        assert np.abs(got - ref).max() < 5e-6
