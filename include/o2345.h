@@ -242,6 +242,12 @@ int o2345_color_points_x3(const float* blob, const float* vol_cl, const float* m
  * geometry_feat [P,16], rgb_feat [V,P,59] (colours | features), ray_diff [V,P,4], mask [V,P] (non-zero = valid) -> rgb [P,3] and the number of
  * valid views [P] (optional).  blob: the x3 (x3 = 1) or fp32-MFMA (x3 = 0) packing of the network.  The fused Projector path above is the fast
  * one; this entry makes the network a drop-in on its own (any Projector). */
+/* Projector.compute (query_cam) / compute_view_independent (normals) MATERIALISED (models/projector.py:96-425): the four tensors of
+ * GeneralRenderingNetwork.forward in the reference's layout -- geometry_feat [P,16], rgb_feat [V,P,59], ray_diff [V,P,4], mask [V,P] (1 / 0).
+ * For callers that want the tensors themselves (a foreign rendering network); the fused o2345_color_points_* never store them. */
+int o2345_project_features(const float* vol_cl, const float* maskvol, int D, const float* cmaps, const float* proj, const float* cam_pos, int V,
+                           int H, int W, const float* pts, long long P, const float* query_cam, const float* normals, float* geometry_feat,
+                           float* rgb_feat, float* ray_diff, float* mask, void* stream);
 int o2345_color_from_features(const float* blob, int x3, const float* geometry_feat, const float* rgb_feat, const float* ray_diff,
                               const float* mask, int V, long long P, float* out_rgb, uint8_t* out_nviews, void* stream);
 

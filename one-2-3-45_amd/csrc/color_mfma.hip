@@ -343,6 +343,18 @@ int o2345_color_points_mfma(const float* blob, const float* vol_cl, const float*
     return color_mfma_launch(false, blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews, stream);
 }
 
+// Projector.compute (query_cam) / compute_view_independent (normals) materialised: geometry_feat [P,16], rgb_feat [V,P,59], ray_diff [V,P,4],
+// mask [V,P] (1 / 0) in the reference's view-major layout (models/projector.py:96-425)
+int o2345_project_features(const float* vol_cl, const float* maskvol, int D, const float* cmaps, const float* proj, const float* cam_pos, int V, int H,
+                           int W, const float* pts, long long P, const float* query_cam, const float* normals, float* geometry_feat, float* rgb_feat,
+                           float* ray_diff, float* mask, void* stream) {
+    O2345_REQUIRE(vol_cl && maskvol && cmaps && proj && cam_pos && pts && geometry_feat && rgb_feat && ray_diff && mask, "project_features: null pointer");
+    O2345_REQUIRE((query_cam != nullptr) != (normals != nullptr), "project_features: give exactly one of query_cam / normals");
+    O2345_REQUIRE(V >= 1 && P >= 0 && P * V < (1ll << 33), "project_features: bad sizes");
+    if (P == 0) return 0;
+    return project_features_launch(vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, P, query_cam, normals, geometry_feat, rgb_feat, ray_diff, mask, stream);
+}
+
 // GeneralRenderingNetwork.forward(geometry_feat, rgb_feat, ray_diff, mask) on materialised tensors in the reference's layout (view-major):
 // geometry_feat [P,16], rgb_feat [V,P,59], ray_diff [V,P,4], mask [V,P] (non-zero = valid) -> rgb [P,3], number of valid views [P].
 // x3 = 1: blob from weights.pack_color_x3_blob (split-f16 form), 0: weights.pack_color_mfma_blob (fp32 MFMA).

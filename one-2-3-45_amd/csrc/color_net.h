@@ -211,6 +211,9 @@ __device__ __forceinline__ void cm_project(const float* __restrict__ P, float x,
 
 
 // csrc/color_pts.hip: the points-as-columns kernel (default); O2345_COLOR_KERNEL=tiles selects k_color_mfma (csrc/color_mfma.hip)
+int project_features_launch(const float* vol_cl, const float* maskvol, int D, const float* cmaps, const float* proj, const float* cam_pos, int V, int H, int W,
+                            const float* pts, long long n, const float* query_cam, const float* normals, float* geo, float* rgb_feat, float* rdiff, float* mask,
+                            void* stream);
 int color_feats_launch(int x3, const float* blob, const float* geo, const float* rgb_feat, const float* ray_diff, const float* mask, int V, long long n,
                        float* out_rgb, uint8_t* out_nviews, void* stream);
 int color_pts_launch(int x3, const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps, const float* proj,

@@ -372,6 +372,65 @@ int color_pts_launch(int x3, const float* blob, const float* vol_cl, const float
     return check_launch("color_points (points-as-columns kernel)");
 }
 
+// Projector.compute / compute_view_independent MATERIALISED (models/projector.py:96-425): the four tensors the reference's own
+// GeneralRenderingNetwork.forward takes, in its layout.  One wave per (point, view), lane = channel of the 64-float pixel.  Only for callers that
+// want the tensors (a foreign rendering network); the fused kernels above never store them.
+__global__ __launch_bounds__(256) void k_project_features(ColorMArgs a, float* __restrict__ geo /*[P,16]*/, float* __restrict__ rgb_feat /*[V,P,59]*/,
+                                                          float* __restrict__ rdiff /*[V,P,4]*/, float* __restrict__ mask /*[V,P]*/) {
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= a.n * a.V) return;
+    const long long p = w / a.V;
+    const int v = (int)(w - p * a.V), c = threadIdx.x & 63;
+    const float px = a.pts[3 * p], py = a.pts[3 * p + 1], pz = a.pts[3 * p + 2];
+    float msum = 0.f, gch = 0.f;
+    {
+        const Axis2 ax = axis_taps_zeros(px, a.D), ay = axis_taps_zeros(py, a.D), az = axis_taps_zeros(pz, a.D);
+#pragma unroll
+        for (int tap = 0; tap < 8; ++tap) {
+            const int ia = (tap >> 2) & 1, ib = (tap >> 1) & 1, ic = tap & 1;
+            const float wt = ax.w[ia] * ay.w[ib] * az.w[ic];
+            if (wt != 0.f) {
+                const size_t vox = ((size_t)ax.i[ia] * a.D + ay.i[ib]) * a.D + az.i[ic];
+                msum += wt * a.maskvol[vox];
+                if (c < 16) gch = fmaf(a.vol_cl[vox * 16 + c], wt, gch);
+            }
+        }
+    }
+    const bool gvalid = fabsf(px) < 1.f && fabsf(py) < 1.f && fabsf(pz) < 1.f && msum > 0.f;
+    float qx, qy, qz;
+    if (a.normals) {
+        const float nx = a.normals[3 * p], ny = a.normals[3 * p + 1], nz = a.normals[3 * p + 2];
+        const float rn = crcp(fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-6f));
+        qx = nx * rn; qy = ny * rn; qz = nz * rn;
+    } else {
+        const float tx = a.query_cam[0] - px, ty = a.query_cam[1] - py, tz = a.query_cam[2] - pz;
+        const float rn = crcp(sqrtf(tx * tx + ty * ty + tz * tz) + 1e-6f);
+        qx = tx * rn; qy = ty * rn; qz = tz * rn;
+    }
+    const ViewGeom g = view_geom(a, v, px, py, pz, qx, qy, qz, gvalid, 0.f);
+    float val = 0.f;
+    {
+        const Taps2D tp = bilinear_taps(g.gx, g.gy, a.H, a.W_img);
+        const float* img = a.cmaps + (size_t)v * a.H * a.W_img * 64 + c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tp.w[k] != 0.f) val = fmaf(img[(size_t)tp.idx[k] * 64], tp.w[k], val);
+    }
+    const size_t vp = (size_t)v * a.n + p;
+    if (c < 59) rgb_feat[vp * 59 + c] = val;
+    if (c < 4) rdiff[vp * 4 + c] = g.rd[c];
+    if (c == 0) mask[vp] = g.m;
+    if (v == 0 && c < 16) geo[(size_t)p * 16 + c] = gch;
+}
+
+int project_features_launch(const float* vol_cl, const float* maskvol, int D, const float* cmaps, const float* proj, const float* cam_pos, int V, int H, int W,
+                            const float* pts, long long n, const float* query_cam, const float* normals, float* geo, float* rgb_feat, float* rdiff, float* mask,
+                            void* stream) {
+    ColorMArgs a{nullptr, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, nullptr, nullptr, n, query_cam, normals, nullptr, nullptr};
+    hipLaunchKernelGGL(k_project_features, dim3(cdiv(n * V, 4)), dim3(256), 0, (hipStream_t)stream, a, geo, rgb_feat, rdiff, mask);
+    return check_launch("project_features");
+}
+
 // GeneralRenderingNetwork.forward on the reference's materialised tensors (the drop-in form; the fused Projector path above is the fast one)
 int color_feats_launch(int x3, const float* blob, const float* geo, const float* rgb_feat, const float* ray_diff, const float* mask, int V, long long n,
                        float* out_rgb, uint8_t* out_nviews, void* stream) {

@@ -438,6 +438,22 @@ def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=Non
 
 
 @_on_device
+def project_features(vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=None, normals=None):
+    """Projector.compute (query_cam) / compute_view_independent (normals) materialised in the reference's layout:
+    -> geometry_feat [P,16], rgb_feat [V,P,59], ray_diff [V,P,4], mask [V,P] (1 / 0)."""
+    V, H, W, _ = cmaps.shape
+    P = pts.shape[0]
+    dev = pts.device
+    geo = torch.empty(P, 16, dtype=torch.float32, device=dev)
+    rf = torch.empty(V, P, 59, dtype=torch.float32, device=dev)
+    rd = torch.empty(V, P, 4, dtype=torch.float32, device=dev)
+    m = torch.empty(V, P, dtype=torch.float32, device=dev)
+    check(_lib.lib().o2345_project_features(_p(vol_cl), _p(maskvol), vol_cl.shape[0], _p(cmaps), _p(proj), _p(cam_pos), V, H, W, _p(pts), P, _p(query_cam),
+                                            _p(normals), _p(geo), _p(rf), _p(rd), _p(m), _stream()), "project_features")
+    return geo, rf, rd, m
+
+
+@_on_device
 def color_from_features(blob, geometry_feat, rgb_feat, ray_diff, mask, x3=True, want_nviews=True):
     """GeneralRenderingNetwork.forward on materialised tensors in the reference's layout: geometry_feat [P,16], rgb_feat [V,P,59],
     ray_diff [V,P,4], mask [V,P] -> (rgb [P,3], valid views uint8 [P]).  blob: pack_color_x3_blob (x3) or pack_color_mfma_blob."""

@@ -20,6 +20,15 @@ class DeferredColour:
     def detach(self):
         return self
 
+    def materialise(self):
+        """The reference Projector's own four tensors for these points (models/projector.py:96-425): geometry_feat [R,S,16], rgb_feat [V,R,S,59],
+        ray_diff [V,R,S,4], mask [V,R,S] -- for a caller that feeds a rendering network other than ours."""
+        R, S = self.shape
+        geo, rf, rd, m = ops.project_features(self.vol_cl, self.maskvol, self.cmaps, self.proj, self.cam_pos, self.pts,
+                                              query_cam=getattr(self, "query_cam", None), normals=getattr(self, "normals", None))
+        V = rf.shape[0]
+        return geo.view(R, S, 16), rf.view(V, R, S, 59), rd.view(V, R, S, 4), m.view(V, R, S)
+
 
 class GeneralRenderingNetwork(nn.Module):
     def __init__(self, in_geometry_feat_ch=8, in_rendering_feat_ch=56, anti_alias_pooling=True):

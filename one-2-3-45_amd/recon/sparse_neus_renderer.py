@@ -24,7 +24,15 @@ def _scene_maps(feature_maps, color_maps, w2cs, intrinsics):
 
 class Projector:
     """compute / compute_view_independent return (DeferredColour, None, None, None, None, None): the reference's callers pass the
-    first four entries straight to GeneralRenderingNetwork.forward (sparse_neus_renderer.py:311-338, trainer_generic.py:1330-1352)."""
+    first four entries straight to GeneralRenderingNetwork.forward (sparse_neus_renderer.py:311-338, trainer_generic.py:1330-1352).
+    With ``materialise = True`` they return the reference's own four tensors instead (for a rendering network that is not ours)."""
+
+    materialise = False
+
+    def _result(self, h):
+        if self.materialise:
+            return h.materialise() + (None, None)
+        return h, None, None, None, None, None
 
     def _handle(self, pts, geometryVolume, geometryVolumeMask, rendering_feature_maps, color_maps, w2cs, intrinsics, **kw):
         if pts.dim() == 2:
@@ -42,7 +50,7 @@ class Projector:
             raise NotImplementedError("o2345 Projector.compute: pass query_c2w (the runner always does)")
         h = self._handle(pts, geometryVolume, geometryVolumeMask, rendering_feature_maps, color_maps, w2cs, intrinsics,
                          query_cam=query_c2w.reshape(-1, 4, 4)[0, :3, 3].contiguous().float(), normals=None)
-        return h, None, None, None, None, None
+        return self._result(h)
 
     def compute_view_independent(self, pts, geometryVolume=None, geometryVolumeMask=None, sdf_network=None, lod=0, vol_dims=None,
                                  partial_vol_origin=None, vol_size=None, rendering_feature_maps=None, color_maps=None, w2cs=None,
@@ -52,7 +60,7 @@ class Projector:
         grad = sdf_network.gradient(p.contiguous().float(), geometryVolume[None] if geometryVolume.dim() == 4 else geometryVolume, lod).squeeze(1)
         h = self._handle(pts, geometryVolume, geometryVolumeMask, rendering_feature_maps, color_maps, w2cs, intrinsics,
                          query_cam=None, normals=grad.contiguous())
-        return h, None, None, None, None, None
+        return self._result(h)
 
 
 class SparseNeuSRenderer(nn.Module):

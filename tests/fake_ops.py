@@ -251,6 +251,15 @@ def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=Non
     return rgb, nv
 
 
+def project_features(vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=None, normals=None):
+    D = vol_cl.shape[0]
+    fm, cm = _maps(cmaps)
+    nrm = None if normals is None else F.normalize(normals, p=2, dim=-1, eps=1e-6)
+    geo, rf, rd, vm = O.projector(pts, vol_cl.permute(3, 0, 1, 2), maskvol.view(D, D, D), fm, cm, None, None, (cmaps.shape[2], cmaps.shape[1]),
+                                  query_cam=query_cam, normals=nrm, proj=proj, cam_pos=cam_pos)
+    return geo, rf.contiguous(), rd.contiguous(), vm.float()
+
+
 def color_from_features(blob, geometry_feat, rgb_feat, ray_diff, mask, x3=True, want_nviews=True):
     c, n = O.rendering_network(_COL[blob.data_ptr()], geometry_feat, rgb_feat, ray_diff, mask > 0)
     return c, (n.to(torch.uint8) if want_nviews else None)
@@ -300,7 +309,7 @@ def install(monkeypatch):
     costreg = importlib.import_module("one-2-3-45_amd.costreg")
     featurenet = importlib.import_module("one-2-3-45_amd.featurenet")
     for name in ("costvol_index", "costvol_gather", "visible_count_list", "costvol_gather_list", "build_index_grid", "scatter_dense", "sdf_mlp",
-                 "pack_color_maps", "color_points", "color_from_features", "render_rays", "marching_cubes", "prune_dilate", "sparse_downsample", "sparse_conv3d", "bn_act_rows", "fpn_level", "pyramid_pack", "conv2d", "conv2d_pack", "conv_x3", "scale_shift_act", "sdf_grid_tables"):
+                 "pack_color_maps", "color_points", "color_from_features", "project_features", "render_rays", "marching_cubes", "prune_dilate", "sparse_downsample", "sparse_conv3d", "bn_act_rows", "fpn_level", "pyramid_pack", "conv2d", "conv2d_pack", "conv_x3", "scale_shift_act", "sdf_grid_tables"):
         monkeypatch.setattr(ops, name, globals()[name])
     spnn = importlib.import_module("one-2-3-45_amd.shims.torchsparse.nn")
     monkeypatch.setattr(spnn, "_require_device", lambda t: None)

@@ -143,6 +143,18 @@ def test_rendering_network_on_materialised_tensors(S):
                            T(vm.float().numpy()).view(V, -1, 12))
     assert col.shape == col_fused.shape and torch.equal(valid, valid_fused)
     assert float((col - col_fused).abs().max()) < 2e-5
+    # and the mirror Projector hands out the same four tensors itself when asked to materialise
+    S["ren"].rendering_projector.materialise = True
+    try:
+        a2, b2, c2, d2, _, _ = S["ren"].rendering_projector.compute(
+            T(pts.numpy()).view(-1, 12, 3), geometryVolume=dense[0], geometryVolumeMask=mask[0], rendering_feature_maps=T(G["fmaps"]),
+            color_maps=T(sc["images"]), w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW], query_img_idx=0, query_c2w=T(sc["query_c2w"])[None])
+    finally:
+        S["ren"].rendering_projector.materialise = False
+    assert a2.shape == (pts.shape[0] // 12, 12, 16) and b2.shape == (V, pts.shape[0] // 12, 12, 59) and d2.shape == (V, pts.shape[0] // 12, 12)
+    assert rel(b2.reshape(V, -1, 59), rf.numpy()) < 3e-5 and rel(c2.reshape(V, -1, 4), rd.numpy()) < 3e-5     # (the mirror multiplies K and w2c in fp32 first)
+    col2, valid2 = S["rnet"](a2, b2, c2, d2)
+    assert torch.equal(valid2, valid_fused) and float((col2 - col_fused).abs().max()) < 2e-5
 
 
 def test_mcubes_shim(S):

@@ -197,6 +197,17 @@ def test_color_from_materialised_features(dev, ops, prec, V):
     close(rgb, fused, rel=2e-5, what="materialised vs fused inputs")
     with pytest.raises(ValueError, match="expected geometry_feat"):
         ops.color_from_features(blob, geo.to(dev), rf[..., :58].contiguous().to(dev), rd.contiguous().to(dev), vm.float().to(dev), x3=x3)
+    # the materialising Projector (o2345_project_features) reproduces the oracle projector's four tensors, and feeds the network kernel
+    g2, rf2, rd2, m2 = ops.project_features(d["vol_cl"], d["maskvol"], d["cmaps"], d["proj"], d["cam_pos"], pts.to(dev), query_cam=qcam.to(dev))
+    assert torch.equal(m2.cpu() > 0, vm)
+    close(g2, geo, rel=2e-5, what="geometry_feat"); close(rf2, rf, rel=2e-5, what="rgb_feat"); close(rd2, rd, rel=2e-5, what="ray_diff")
+    rgb3, nv3 = ops.color_from_features(blob, g2, rf2, rd2, m2, x3=x3)
+    assert torch.equal(nv3.cpu().float(), nv_ref)
+    close(rgb3, fused, rel=2e-5, what="materialised by the HIP projector vs fused")
+    nrm = torch.from_numpy(rng.normal(0, 1, (pts.shape[0], 3)).astype(np.float32))
+    g4, rf4, rd4, m4 = ops.project_features(d["vol_cl"], d["maskvol"], d["cmaps"], d["proj"], d["cam_pos"], pts.to(dev), normals=nrm.to(dev))
+    _, _, rd_ref, _ = O.projector(pts, s["dense"][0], s["mask"][0, 0], fm, im, w2c, Kt, (s["W"], s["H"]), normals=torch.nn.functional.normalize(nrm, p=2, dim=-1, eps=1e-6))
+    close(rd4, rd_ref, rel=2e-5, what="ray_diff (view-independent)")
 
 
 CONV_SHAPES = [(3, 8, 3, 1), (8, 8, 3, 1), (8, 16, 5, 2), (16, 16, 3, 1), (16, 32, 5, 2), (32, 32, 3, 1), (32, 32, 1, 1), (32, 16, 3, 1), (32, 8, 3, 1),
