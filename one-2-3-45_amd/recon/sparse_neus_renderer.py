@@ -133,14 +133,14 @@ class SparseNeuSRenderer(nn.Module):
                                       "per-ray near / far are not supported")
         nr, fr = float(nt[0]), float(ft[0])
         o = ops.render_rays(scene, rays_o.contiguous().float(), rays_d.contiguous().float(), nr, fr, self.n_samples, self.n_importance,
-                            inv_s, float(alpha_inter_ratio), 1.0 if background_rgb is None else float(background_rgb),
+                            inv_s, float(alpha_inter_ratio), 0.0 if background_rgb is None else float(background_rgb),    # None: nothing is added (:430-431)
                             query_c2w.reshape(-1, 4, 4)[0, :3, 3].contiguous().float(), t_rand=t_rand)
         S = self.n_samples + self.n_importance
         pm = o["pm"].t()
         ge = o["grad_err"].sum(0)
         pts_random = torch.rand([1024, 3], device=rays_o.device) * 2 - 1
         sdf_random = sdf_network.sdf(pts_random, conditional_volume, lod=lod)["sdf_pts_scale%d" % lod]
-        color = o["color"] if background_rgb is not None else o["color"] - (1.0 - o["weights_sum"])[:, None]
+        color = o["color"]
         return {"depth": o["depth"][:, None], "color_fine": color, "color_fine_mask": o["color_mask"].bool()[:, None], "color_outside": None,
                 "color_outside_mask": None, "color_mlp": None, "color_mlp_mask": None, "variance": torch.tensor(1.0 / inv_s, device=rays_o.device),
                 "cdf_fine": o["cdf"].t(), "depth_variance": o["depth_var"][:, None], "weights_sum": o["weights_sum"][:, None],

@@ -317,8 +317,9 @@ def sdf_mlp(pts, latent, W):
     return torch.cat([h, latent], 1) @ W["w2"].T + W["b2"]
 
 
-SDF_NOISE = None      # (relative sigma, torch.Generator) or None.  Sensitivity probe ONLY (tests/fullsize_util.py): multiplies the SDF
-                      # output by (1 + sigma * N(0,1)) to measure how the hierarchical sampler amplifies fp32-class SDF differences.
+SDF_NOISE = None      # (relative sigma, torch.Generator[, absolute sigma]) or None.  Sensitivity probe ONLY (tests/fullsize_util.py,
+                      # tests/render_check.py): multiplies the SDF output by (1 + sigma * N(0,1)) and adds abs_sigma * N(0,1) to measure how the
+                      # reference ALGORITHM (hierarchical sampler, sigmoids of slope inv_s) amplifies fp32-class SDF differences.
 
 
 def sdf(pts, volume, W):
@@ -326,8 +327,11 @@ def sdf(pts, volume, W):
     lat = trilinear_ref(volume, pts)
     y = sdf_mlp(pts, lat, W)
     if SDF_NOISE is not None:
-        sigma, gen = SDF_NOISE
-        y = torch.cat([y[:, :1] * (1 + sigma * torch.randn(y.shape[0], 1, generator=gen)), y[:, 1:]], 1)
+        sigma, gen = SDF_NOISE[:2]
+        y0 = y[:, :1] * (1 + sigma * torch.randn(y.shape[0], 1, generator=gen))
+        if len(SDF_NOISE) > 2:
+            y0 = y0 + SDF_NOISE[2] * torch.randn(y.shape[0], 1, generator=gen)
+        y = torch.cat([y0, y[:, 1:]], 1)
     return y, lat
 
 
@@ -626,3 +630,49 @@ def costvol_list(feats, P, xyz, voxel_size, origin):
 def sparse_costreg_unordered(feat, coords, w):
     """SparseCostRegNet on an arbitrary-order coordinate list (lod 1): same maths as sparse_costreg, rows stay in input order."""
     return sparse_costreg(feat, coords, w)
+
+
+# ----------------------------------------------------------------------------------------------
+# f1: FeatureNet (models/featurenet.py:40-91) + the fused pyramid of GenericTrainer.obtain_pyramid_feature_maps
+#     (models/trainer_generic.py:1104-1125) + the compress layer (sparse_sdf_network.py:171-173, 312).
+#     sd = the reference module's own state dict (conv0.0.conv.weight, conv0.0.bn.{weight,bias}, toplayer.{weight,bias}, ...).
+#     Pinned to the reference's FeatureNet by tests/golden/ref_featurenet.npz (tests/test_golden_oracle.py).
+# ----------------------------------------------------------------------------------------------
+def conv_abn(x, sd, prefix, stride=1):
+    """ConvBnReLU (featurenet.py:12-22): Conv2d without bias, padding = k // 2, then InPlaceABN with batch statistics (the runner
+    never calls .eval(): SURVEY finding 5)."""
+    w = sd[prefix + ".conv.weight"]
+    y = F.conv2d(x, w, None, stride=stride, padding=w.shape[-1] // 2)
+    return abn_train(y, sd[prefix + ".bn.weight"], sd[prefix + ".bn.bias"])
+
+
+def featurenet(imgs, sd):
+    """[V,3,H,W] -> [feat2 (32 @ H/4), feat1 (16 @ H/2), feat0 (8 @ H)], featurenet.py:68-91."""
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True)
+    lin = lambda t, name, pad=0: F.conv2d(t, sd[name + ".weight"], sd[name + ".bias"], padding=pad)
+    c0 = conv_abn(conv_abn(imgs, sd, "conv0.0"), sd, "conv0.1")
+    c1 = conv_abn(conv_abn(conv_abn(c0, sd, "conv1.0", 2), sd, "conv1.1"), sd, "conv1.2")
+    c2 = conv_abn(conv_abn(conv_abn(c1, sd, "conv2.0", 2), sd, "conv2.1"), sd, "conv2.2")
+    f2 = lin(c2, "toplayer")
+    f1 = up(f2) + lin(c1, "lat1")
+    f0 = up(f1) + lin(c0, "lat0")
+    return [f2, lin(f1, "smooth1", 1), lin(f0, "smooth0", 1)]
+
+
+def fused_pyramid(imgs, sd):
+    """trainer_generic.py:1117-1123: cat(x4 bilinear of feat2, x2 bilinear of feat1, feat0) -> [V,56,H,W]."""
+    f2, s1, s0 = featurenet(imgs, sd)
+    return torch.cat([F.interpolate(f2, scale_factor=4, mode="bilinear", align_corners=True),
+                      F.interpolate(s1, scale_factor=2, mode="bilinear", align_corners=True), s0], 1)
+
+
+def conditional_volume(imgs, feat_sd, compress_sd, costreg_w, P, dims, voxel_size, origin, fmaps=None):
+    """get_conditional_volume at lod 0 from the IMAGES (sparse_sdf_network.py:286-400 behind trainer_generic.py:1104-1125):
+    FeatureNet -> fused pyramid -> compress layer -> back-projection + aggregation -> SparseCostRegNet -> dense scatter.
+    -> dict(fmaps [V,56,H,W], feats16 [V,16,H,W], coords [N,3], rows [N,32], rows16 [N,16], dense [1,16,D,D,D], mask [1,1,D,D,D])."""
+    fmaps = fused_pyramid(imgs, feat_sd) if fmaps is None else fmaps
+    f16 = abn_train(F.conv2d(fmaps, compress_sd["conv.weight"], None, padding=1), compress_sd["bn.weight"], compress_sd["bn.bias"])
+    coords, rows, cnt = costvol(f16, P, dims, voxel_size, origin)
+    rows16, extra = sparse_costreg(rows, coords, costreg_w)
+    dense, mask = scatter_dense(coords, rows16, dims)
+    return dict(fmaps=fmaps, feats16=f16, coords=coords, rows=rows, cnt=cnt, rows16=rows16, dense=dense, mask=mask, levels=extra["levels"])

@@ -90,6 +90,47 @@ def main_perturb(seed=1234):
           float(np.abs(out["ren_color_fine"] - g0["ren_color_fine"]).max()))
 
 
+TRAINED = ((0.62, 0.5, None), (0.45, 0.0, 1.0), (0.65, 1.0, None), (0.2, 0.5, None))     # (variance, alpha_inter_ratio, background_rgb)
+TRAINED_SDF_SHIFT = -0.3      # added to the SDF output bias (sdf_layer.lin2.bias[0]): moves the zero level set of the seeded field into the rays'
+                              # valid range (min SDF over the valid samples of ref_small.npz is 0.117), so that sharp sigmoids have a surface to find
+
+
+def main_trained():
+    """tests/golden/ref_trained.npz: the reference's render() in the regime of a TRAINED model -- SingleVarianceNetwork far from its
+    init (variance 0.45 / 0.62 / 0.65 -> inv_s = exp(10 v) = 90 / 493 / 665, models/fields.py:179-186), the iter_step-driven
+    alpha_inter_ratio of exp_runner_generic_blender_val.py:412-418 (0, 0.5, 1) and background_rgb None / 1.0 (train.use_white_bkgd) --
+    on the ref_small.npz scene, deterministic sampling (perturb_overwrite = 0)."""
+    torch.set_grad_enabled(False)
+    cfg = CFG
+    sc, fmaps, pts, ro, rd = inputs()
+    HW = cfg["HW"]
+    sdfnet, rnet, var, renderer = networks(cfg)
+    T = torch.from_numpy
+    here = os.path.dirname(os.path.abspath(__file__))
+    g0 = np.load(os.path.join(here, "ref_small.npz"))
+    dense, mask = T(g0["dense"])[None], T(g0["mask"])[None, None]
+    sdfnet.sdf_layer.lin2.bias.data[0] += TRAINED_SDF_SHIFT
+    near, far = T(sc["query_near_far"][:1]), T(sc["query_near_far"][1:])
+    out = {"sdf_shift": np.float64(TRAINED_SDF_SHIFT), "combos": np.array([[v, a, -1.0 if b is None else b] for v, a, b in TRAINED], np.float64)}
+    seen_z = []
+    core = renderer.render_core
+    renderer.render_core = lambda ro_, rd_, z_, *a, **k: (seen_z.append(z_.clone()), core(ro_, rd_, z_, *a, **k))[1]     # record the sample lists
+    for i, (v, air, bg) in enumerate(TRAINED):
+        var.variance.data = torch.tensor(v)
+        ren = renderer.render(T(ro), T(rd), near, far, sdfnet, rnet, perturb_overwrite=0, background_rgb=bg, alpha_inter_ratio=air,
+                              lod=0, conditional_volume=dense, conditional_valid_mask_volume=mask, feature_maps=T(fmaps),
+                              color_maps=T(sc["images"]), w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW],
+                              query_c2w=T(sc["query_c2w"])[None], if_render_with_grad=False)
+        for k in ("color_fine", "depth", "weights", "weights_sum", "depth_variance", "cdf_fine", "color_fine_mask", "weights_max"):
+            out[f"c{i}_{k}"] = ren[k].numpy()
+        out[f"c{i}_z_vals"] = seen_z[-1].numpy()                  # what render() handed to render_core (sparse_neus_renderer.py:559)
+        print(f"variance {v} (inv_s {float(np.exp(10 * v)):.1f}) air {air} bg {bg}: weights_sum max {float(ren['weights_sum'].max()):.4f} "
+              f"weights_max max {float(ren['weights_max'].max()):.4f}")
+    path = os.path.join(here, "ref_trained.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main_featurenet(seed=21):
     """tests/golden/ref_featurenet.npz: the reference's FeatureNet (models/featurenet.py:40-91, InPlaceABN = the functional stand-in of
     oracle/ref_import.py) and the fused pyramid of GenericTrainer.obtain_pyramid_feature_maps (trainer_generic.py:1117-1123) on seeded images."""
@@ -201,4 +242,11 @@ def main():
 
 
 if __name__ == "__main__":
-    main_perturb() if "--perturb" in sys.argv else (main_featurenet() if "--featurenet" in sys.argv else main())
+    if "--perturb" in sys.argv:
+        main_perturb()
+    elif "--featurenet" in sys.argv:
+        main_featurenet()
+    elif "--trained" in sys.argv:
+        main_trained()
+    else:
+        main()

@@ -311,3 +311,195 @@ def test_fullsize_numerical_forms_agree(full):
     ds = (a["sdf"] - b["sdf"]).abs()[same & (a["pm"] > 0)]
     # 29 M points: the maximum approaches the worst case of the split form (144 same-signed terms x 2^-22), the mean is fp32 rounding noise
     assert float(ds.max()) < 2e-4 and float(ds.mean()) < 3e-6 and float(same.float().mean()) > 0.9
+
+
+# ------------------------------------------------------------------------------- oracle parity of the VOLUME BUILD at the benchmarked size
+def _oracle_weight_dicts(wt):
+    from scene_util import costreg_oracle_weights
+    fsd = {k: v.detach().cpu() for k, v in wt.featurenet.state_dict().items()}
+    csd = {k: v.detach().cpu() for k, v in wt.compress.state_dict().items()}
+    return fsd, csd, costreg_oracle_weights(wt.costreg_sd)
+
+
+@pytest.fixture(scope="module")
+def oracle_volume(full):
+    """The ORACLE's own get_conditional_volume from the IMAGES at BASELINE config-2 size (8 x 256^2 views, 128^3): FeatureNet -> fused pyramid ->
+    compress layer -> back-projection + aggregation over 2.1 M voxels -> sparse CNN on 1.17 M voxels -> dense scatter (oracle/recon.py,
+    ~30 GFLOP on the host: tens of seconds)."""
+    sc, D = full["sc"], full["D"]
+    fsd, csd, cw = _oracle_weight_dicts(full["wt"])
+    with torch.no_grad():
+        return O.conditional_volume(torch.from_numpy(sc["images"]), fsd, csd, cw, torch.from_numpy(sc["affine_mats"]), [D, D, D], 2.0 / (D - 1),
+                                    torch.from_numpy(sc["partial_vol_origin"]))
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+
+
+def test_fullsize_volume_vs_oracle(full, oracle_volume):
+    """HIP volume build vs the oracle at the BENCHMARKED size (sparse_sdf_network.py:286-400, tsparse/modules.py:259-304): kept-voxel set and
+    visible-view counts exact, every intermediate tensor and the dense latent volume within fp32 tolerances."""
+    vol, ov, D = full["vol"], oracle_volume, full["D"]
+    assert torch.equal(vol["coords"].cpu(), ov["coords"])                                         # 1,166,970 kept voxels: exact, same order
+    assert torch.equal(vol["cnt"].cpu().long().view(-1), ov["cnt"].long().view(-1))               # visible-view count of all 128^3 voxels
+    assert torch.equal(vol["maskvol"].view(D, D, D).cpu(), ov["mask"][0, 0])
+    r = {"fused_pyramid": _rel(vol["cmaps"][..., 3:59].permute(0, 3, 1, 2), ov["fmaps"]),
+         "compressed_maps": _rel(vol["feats_nhwc"].permute(0, 3, 1, 2), ov["feats16"]),
+         "cost_volume_rows": _rel(vol["rows"], ov["rows"]), "sparse_cnn_rows": _rel(vol["rows16"], ov["rows16"]),
+         "dense_volume": _rel(vol["vol_cl"].permute(3, 0, 1, 2)[None], ov["dense"])}
+    print("full-size volume build vs oracle (max abs error / max|oracle|):", r)
+    assert r["fused_pyramid"] < 5e-5 and r["compressed_maps"] < 5e-5 and r["cost_volume_rows"] < 1e-4, r
+    assert r["sparse_cnn_rows"] < 1e-4 and r["dense_volume"] < 1e-4, r
+
+
+def _oracle_args_from(ov_dense, ov_mask, fmaps, wt, sc):
+    """Oracle argument dict for tests/render_check.py from CPU tensors (dense [1,16,D,D,D], mask [1,1,D,D,D], fmaps [V,56,H,W])."""
+    H, Wd = sc["images"].shape[2:]
+    return dict(volume=ov_dense[0].contiguous(), maskvol=ov_mask[0, 0].contiguous(), W={k: torch.from_numpy(np.asarray(v)) for k, v in wt.sdfW.items()},
+                RW={k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in wt.color_sd.items()}, feat_maps=fmaps.contiguous(),
+                color_maps=torch.from_numpy(sc["images"]), w2cs=torch.from_numpy(sc["w2cs"]), K=torch.from_numpy(sc["intrinsics"]),
+                img_wh=(Wd, H), query_c2w=torch.from_numpy(sc["query_c2w"]))
+
+
+def _scene_from(wt, vol_cl, maskvol, cmaps, proj, cam_pos):
+    return dict(sdf_blob=wt.sdf_blob, color_blob=wt.color_blob, color_mfma_blob=wt.color_mblob, color_x3_blob=wt.color_xblob, vol_cl=vol_cl,
+                maskvol=maskvol, cmaps=cmaps, proj=proj, cam_pos=cam_pos)
+
+
+def _spread(n_total, n):
+    return torch.from_numpy(np.unique(np.linspace(0, n_total - 1, n).astype(np.int64)))
+
+
+def test_fullsize_render_on_the_oracle_volume(full, oracle_volume):
+    """The three-clause render contract at BASELINE config 2 with the ORACLE's volume, mask and feature maps on BOTH sides (the other
+    full-size test hands the oracle HIP's volume): the render comparison then isolates the renderer, and together with
+    test_fullsize_volume_vs_oracle the whole path images -> colours is oracle-checked at the benchmarked size."""
+    import render_check as RC
+    sc, wt, ov, T = full["sc"], full["wt"], oracle_volume, full["T"]
+    a = _oracle_args_from(ov["dense"], ov["mask"], ov["fmaps"], wt, sc)
+    cmaps = ops.pack_color_maps(ov["fmaps"].to(dev).contiguous(), T(sc["images"]))
+    scene = _scene_from(wt, ov["dense"][0].permute(1, 2, 3, 0).contiguous().to(dev), ov["mask"].reshape(-1).contiguous().to(dev), cmaps, full["proj"], full["cam_pos"])
+    ro, rd = pkg.synth.gen_rays(sc["query_intrinsic"], sc["query_c2w"], 256, 256, scale=2)
+    sel = _spread(ro.shape[0], 192)
+    res = RC.three_clause(ops, dev, scene, a, torch.from_numpy(ro)[sel], torch.from_numpy(rd)[sel], float(sc["query_near_far"][0]),
+                          float(sc["query_near_far"][1]), 0.2, 1.0, 1.0, "f16x3", chunk=64, label="C2 on the oracle's volume")
+    assert res["rays_hitting_surface"] > 20, res
+
+
+# ------------------------------------------------------------------------------- the other timed configurations, with parity
+@pytest.mark.parametrize("variance", [0.2, 0.6])
+def test_reference_configuration_render_parity(variance):
+    """The REFERENCE's own configuration (confs/one2345_lod0_val_demo.conf: 32 source views, 96^3 volume, one 256 x 256 val image) -- the
+    `ref_config` block of bench.py: three-clause render parity on rays spread over the image (k_color_mfma<32,true>, 32-view cost volume, sparse
+    CNN on ~760 k voxels), at the initial variance and at a trained model's (inv_s = 403)."""
+    import render_check as RC
+    V, D = 32, 96
+    wt = pipeline.SceneWeights(dev, seed=0, variance=variance)
+    sc = pkg.synth.make_scene(V, image_seed=4)
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    vol = pipeline.build_volume(wt, T(sc["images"]), T(sc["affine_mats"]), sc["partial_vol_origin"], D, 2.0 / (D - 1))
+    assert 0.80 * D ** 3 < vol["n_voxels"] < 0.92 * D ** 3                     # SURVEY: 85.9 % of the voxels valid with 32 views
+    proj, cam_pos = pipeline.camera_terms(T(sc["intrinsics"]), T(sc["w2cs"]))
+    fm = vol["cmaps"][..., 3:59].permute(0, 3, 1, 2).contiguous().cpu()
+    a = _oracle_args_from(vol["vol_cl"].permute(3, 0, 1, 2)[None].cpu(), vol["maskvol"].view(1, 1, D, D, D).cpu(), fm, wt, sc)
+    scene = _scene_from(wt, vol["vol_cl"], vol["maskvol"], vol["cmaps"], proj, cam_pos)
+    ro, rd = pkg.synth.gen_rays(sc["query_intrinsic"], sc["query_c2w"], 256, 256)
+    sel = _spread(ro.shape[0], 96)
+    res = RC.three_clause(ops, dev, scene, a, torch.from_numpy(ro)[sel], torch.from_numpy(rd)[sel], float(sc["query_near_far"][0]),
+                          float(sc["query_near_far"][1]), variance, 1.0, 1.0, "f16x3", chunk=32, label="REF V=32 96^3")
+    assert res["rays_hitting_surface"] > 10, res
+    # vertex colours of the export path at this view count (k_color_mfma<32> with normals): a sample of surface points vs the oracle
+    verts, tris, rgb, u = pipeline.extract_mesh(wt, vol, proj, cam_pos, 128)
+    pick = _spread(verts.shape[0], 600).to(dev)
+    p = verts[pick].float().contiguous().cpu()
+    g = O.sdf_grad(p, a["volume"], a["W"])
+    geo, rf, rdf, vm = O.projector(p, a["volume"], a["maskvol"], a["feat_maps"], a["color_maps"], a["w2cs"], a["K"], a["img_wh"],
+                                   normals=torch.nn.functional.normalize(g, p=2, dim=-1, eps=1e-6))
+    want, _ = O.rendering_network(a["RW"], geo, rf, rdf, vm)
+    assert float((rgb[pick].cpu() - want).abs().max()) < 2e-4
+
+
+def test_config5_render_parity():
+    """BASELINE config 5 shape (256^3 volume -- 9.4 M kept voxels through the sparse CNN --, 1024^2 virtual camera): the `config5` block of
+    bench.py.  64 rays spread over the image under the three-clause contract (the oracle reads HIP's 256^3 volume: its own volume build at this
+    size would take minutes), plus the 256^3 kept-voxel set against the oracle's projection test (exact)."""
+    import render_check as RC
+    V, D = 8, 256
+    wt = pipeline.SceneWeights(dev, seed=0)
+    sc = pkg.synth.make_scene(V, image_seed=6)
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    vol = pipeline.build_volume(wt, T(sc["images"]), T(sc["affine_mats"]), sc["partial_vol_origin"], D, 2.0 / (D - 1))
+    assert 0.45 * D ** 3 < vol["n_voxels"] < 0.65 * D ** 3
+    # kept set: the oracle's projection / visibility rule on the full 256^3 lattice (integer result: exact)
+    lat = O.voxel_lattice([D, D, D])
+    cnt = torch.cat([O.project(lat[s:s + (1 << 20)] * (2.0 / (D - 1)) + torch.from_numpy(sc["partial_vol_origin"])[None],
+                               torch.from_numpy(sc["affine_mats"]), 256, 256)[3].sum(1) for s in range(0, lat.shape[0], 1 << 20)])
+    assert torch.equal(vol["cnt"].cpu().long().view(-1), cnt.long())
+    assert torch.equal(vol["coords"][:, :3].cpu().long(), lat[cnt > 1].long())
+    proj, cam_pos = pipeline.camera_terms(T(sc["intrinsics"]), T(sc["w2cs"]))
+    fm = vol["cmaps"][..., 3:59].permute(0, 3, 1, 2).contiguous().cpu()
+    a = _oracle_args_from(vol["vol_cl"].permute(3, 0, 1, 2)[None].cpu(), vol["maskvol"].view(1, 1, D, D, D).cpu(), fm, wt, sc)
+    scene = _scene_from(wt, vol["vol_cl"], vol["maskvol"], vol["cmaps"], proj, cam_pos)
+    ro, rd = pkg.synth.gen_rays(sc["query_intrinsic"], sc["query_c2w"], 256, 256, scale=4)
+    sel = _spread(ro.shape[0], 64)
+    res = RC.three_clause(ops, dev, scene, a, torch.from_numpy(ro)[sel], torch.from_numpy(rd)[sel], float(sc["query_near_far"][0]),
+                          float(sc["query_near_far"][1]), 0.2, 1.0, 1.0, "f16x3", chunk=32, label="C5 256^3")
+    assert res["rays_hitting_surface"] > 5, res
+    del vol, scene
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------- end-to-end mesh agreement
+def test_fullsize_mesh_vs_oracle_field(full):
+    """north_star: "mesh topology exactly ... at matched mesh IoU".  Marching cubes is exact GIVEN u (tests/test_gpu_parity.py); this test closes
+    the loop over the field: on a 64^3 sub-block of the 256^3 extraction lattice that the surface crosses, HIP's u (tabulated-layer-0 lattice
+    kernel, f16x3) vs the oracle's extract_fields (sparse_neus_renderer.py:881-905) -- sign disagreements counted and bounded by the field
+    tolerance (a node may only flip where |u| is within 2e-5 of zero), volumetric IoU of the two inside-sets >= 0.999, and the two meshes of the
+    sub-block (HIP marching cubes on HIP's u, the oracle's marching cubes on the oracle's u) compared: cells whose 8-corner sign pattern
+    agrees produce the same triangles, so topology differs only in the cells listed."""
+    from oracle import mc as omc
+    R, B = 256, 64
+    wt, vol = full["wt"], full["vol"]
+    verts, tris, rgb, u = pipeline.extract_mesh(wt, vol, full["proj"], full["cam_pos"], R)
+    ins = (u > 0)
+    # the sub-block (aligned to 32) with the most sign changes along x
+    chg = (ins[1:] != ins[:-1]).float()
+    best, origin = -1, None
+    for x0 in range(0, R - B + 1, 32):
+        for y0 in range(0, R - B + 1, 32):
+            for z0 in range(0, R - B + 1, 32):
+                c = float(chg[x0:x0 + B - 1, y0:y0 + B, z0:z0 + B].sum())
+                if c > best:
+                    best, origin = c, (x0, y0, z0)
+    x0, y0, z0 = origin
+    lin = torch.linspace(-1, 1, R)
+    gx, gy, gz = torch.meshgrid(lin[x0:x0 + B], lin[y0:y0 + B], lin[z0:z0 + B], indexing="ij")
+    pts = torch.stack([gx, gy, gz], -1).reshape(-1, 3)
+    dense = vol["vol_cl"].permute(3, 0, 1, 2).contiguous().cpu()
+    W = {k: torch.from_numpy(np.asarray(v)) for k, v in wt.sdfW.items()}
+    with torch.no_grad():
+        uo = torch.cat([-O.sdf(pts[s:s + (1 << 16)], dense, W)[0][:, 0] for s in range(0, pts.shape[0], 1 << 16)]).view(B, B, B)
+    uh = u[x0:x0 + B, y0:y0 + B, z0:z0 + B].cpu()
+    err = float((uh - uo).abs().max())
+    flips = (uh > 0) != (uo > 0)
+    nflip = int(flips.sum())
+    inter, union = int(((uh > 0) & (uo > 0)).sum()), int(((uh > 0) | (uo > 0)).sum())
+    iou = inter / max(1, union)
+    print(f"sub-block {origin}: {best:.0f} sign changes, max|u_hip - u_oracle| = {err:.2e}, {nflip} flipped nodes of {B ** 3}, IoU {iou:.6f}; "
+          f"flipped nodes (block coords) {torch.nonzero(flips)[:20].tolist()}, |u| there <= {float(uo[flips].abs().max()) if nflip else 0:.2e}")
+    assert best > 1000 and union > 1000
+    assert err < 2e-5 * max(1.0, float(uo.abs().max()))
+    assert nflip == 0 or float(uo[flips].abs().max()) <= err                      # a node flips only where the field is inside the error band
+    assert iou >= 0.999
+    vh, th = ops.marching_cubes(uh.to(dev).contiguous(), 0.0)
+    vo, to = omc.marching_cubes(uo.numpy(), 0.0)
+    if nflip == 0:
+        assert th.shape[0] == to.shape[0] and vh.shape[0] == vo.shape[0]
+        assert np.array_equal(th.cpu().numpy(), to)                               # identical topology, vertex for vertex
+        d = np.abs(vh.cpu().numpy() - vo).max(1)                                  # crossings slide along their lattice edge with the field error
+        assert float(d.max()) < 0.5 and float(d.mean()) < 1e-3, (float(d.max()), float(d.mean()))
+    else:
+        assert abs(th.shape[0] - to.shape[0]) <= 16 * nflip and abs(vh.shape[0] - vo.shape[0]) <= 12 * nflip

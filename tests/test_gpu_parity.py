@@ -538,3 +538,38 @@ def test_render(dev, ops, nrays, precision):
     bad = torch.nonzero((out["color"].cpu() - ref["color_fine"]).abs().max(1).values > 1e-4)[:, 0]
     print(f"[{precision}, {nrays} rays] colour deviates by > 1e-4 on rays {bad.tolist()} (sample lists differ by {zerr[bad].tolist()})")
     assert bool((zerr[bad] > 1e-6).all())                      # attributable to the sample lists, since (2) is tight for all rays
+
+
+def _oracle_args(s, sdf_shift=0.0):
+    sc = s["sc"]
+    W = sdfW_t(s["sdfW"])
+    if sdf_shift:
+        W = {k: v.clone() for k, v in W.items()}
+        W["b2"][0] += sdf_shift
+    return dict(volume=s["dense"][0], maskvol=s["mask"][0, 0], W=W, RW=color_t(s["color_sd"]), feat_maps=torch.from_numpy(s["fmaps"]),
+                color_maps=torch.from_numpy(sc["images"]), w2cs=torch.from_numpy(sc["w2cs"]), K=torch.from_numpy(sc["intrinsics"]),
+                img_wh=(s["W"], s["H"]), query_c2w=torch.from_numpy(sc["query_c2w"]))
+
+
+@pytest.mark.parametrize("variance,air,bg,shift,precision", [
+    (0.2, 0.0, None, 0.0, "f16x3"), (0.2, 0.5, 1.0, 0.0, "f16x3"), (0.45, 0.5, None, 0.0, "f16x3"), (0.45, 1.0, 1.0, 0.0, "f16x3"),
+    (0.65, 0.0, 1.0, 0.0, "f16x3"), (0.65, 0.5, None, 0.0, "f16x3"), (0.65, 1.0, None, -0.2, "f16x3"), (0.45, 0.0, 1.0, -0.2, "f16x3"),
+    (0.65, 1.0, None, -0.2, "fp32"), (0.45, 0.5, 1.0, 0.0, "fp32")])
+def test_render_trained_regime(dev, ops, variance, air, bg, shift, precision):
+    """render() in the regime of a TRAINED model: SingleVarianceNetwork far from its init (variance 0.45 / 0.65 -> inv_s = 90 / 665,
+    models/fields.py:179-186), the iter_step-driven alpha_inter_ratio of exp_runner_generic_blender_val.py:412-418 (0 / 0.5 / 1),
+    background_rgb None / 1.0 (train.use_white_bkgd), and -- shift = -0.2 -- a field whose zero level set every ray crosses (single-sample
+    weights up to 1.0 at inv_s = 665).  The three-clause contract of tests/render_check.py, all rays, no quantile thresholds."""
+    import render_check as RC
+    s = small_scene()
+    d = dev_scene(s, dev, ops)
+    sc = s["sc"]
+    a = _oracle_args(s, shift)
+    W = {k: np.array(v) for k, v in s["sdfW"].items()}
+    W["b2"][0] += shift
+    scene = {k: d[k] for k in ("color_blob", "color_mfma_blob", "color_x3_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos")}
+    scene["sdf_blob"] = torch.from_numpy(pkg.weights.pack_sdf_blob(W)).to(dev)
+    ro, rd = rays_for(s, 96, seed=5)
+    res = RC.three_clause(ops, dev, scene, a, torch.from_numpy(ro), torch.from_numpy(rd), float(sc["query_near_far"][0]),
+                          float(sc["query_near_far"][1]), variance, air, bg, precision, label="small_scene")
+    assert res["rays_hitting_surface"] > 10, res
