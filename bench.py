@@ -53,6 +53,7 @@ GRAD_MFMA_FLOP_PER_POINT = {"fp32": 896 * 4096 / 32, "f16x3": 348 * 32768 / 32, 
 SDF_FLOP_SDF_ONLY = 2 * (39 * 128 + 144 * 128 + 144)            # 47,136 per point (SDF-only forward)
 SDF_FLOP_GRAD = 2 * SDF_FLOP_SDF_ONLY                          # + ~47,136 for the input gradient (transposed GEMMs)
 COLOR_FLOP_PER_PAIR = 38544                                    # per (point, view)
+COLOR_KERNEL_PREFIX = "k_color_mfma"                            # the colour kernel the default configuration launches (profiles/*_pmc_*.json key prefix)
 
 
 class Timer:
@@ -184,17 +185,32 @@ def network_rooflines(kt, V, sdf_p, col_p):
     }
 
 
-PMC_FILE = "profiles/r02_pmc_f16x3.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_f16x3.json")) else "profiles/r01_pmc_f16x3.json"
+def _pmc_file():
+    """The newest committed counter summary (profiles/rNN_pmc_f16x3.json) and whether it was measured on THIS tree's kernels: the file carries the
+    hash of csrc/* it was collected on (tools/summarize_rocprof.py:provenance); counter-derived numbers are printed only on a match."""
+    import glob
+    build = importlib.import_module("one-2-3-45_amd.build")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_pmc_f16x3.json")))
+    if not files:
+        return None, None, "no profiles/rNN_pmc_f16x3.json"
+    path = files[-1]
+    d = json.load(open(path))
+    want, have = build.sources_sha(), (d.get("_meta") or {}).get("kernel_sources_sha")
+    rel = os.path.relpath(path, ROOT)
+    if have != want:
+        return rel, None, f"{rel} was collected on kernel sources {have} but this tree's csrc/ hashes to {want}: counters not printed (re-run tools/profile_round.sh)"
+    return rel, d, None
+
+
+PMC_FILE, PMC_DATA, PMC_STALE = _pmc_file()
 
 
 def pmc_traffic(kernel_prefix):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (same workload, separate FETCH_SIZE / WRITE_SIZE runs;
-    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  None if absent."""
-    path = os.path.join(ROOT, PMC_FILE)
-    if not os.path.exists(path):
+    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  None if absent or measured on other kernel sources."""
+    if PMC_DATA is None:
         return None
-    d = json.load(open(path))
-    for k, v in d.items():
+    for k, v in PMC_DATA.items():
         if k.startswith(kernel_prefix) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             return (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
     return None
@@ -203,15 +219,13 @@ def pmc_traffic(kernel_prefix):
 def pmc_issue_model(kernel_prefix, ms):
     """What the SIMDs of the dominant kernel spend their time on, from the committed PMC passes (profiles/r02_ubench_issue_model.md: a gfx950 SIMD
     issues EITHER vector OR matrix work, so the matrix-pipe utilisation of an issue-bound kernel is MFMA time / (MFMA + VALU time))."""
-    path = os.path.join(ROOT, PMC_FILE)
-    if not os.path.exists(path):
+    if PMC_DATA is None:
         return None
-    d = json.load(open(path))
-    for k, v in d.items():
+    for k, v in PMC_DATA.items():
         if k.startswith(kernel_prefix) and "SQ_WAVE_CYCLES" in v:
             waves_per_simd = 3.0 if "mfma<" in k else 2.0
             simd_quads = v["SQ_WAVE_CYCLES"] / waves_per_simd                       # summed over the 1024 SIMDs, in quad-cycles
-            return {"source": PMC_FILE, "valu_wave_instructions": v.get("SQ_INSTS_VALU"), "mfma_busy_cycles": v.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+            return {"source": PMC_FILE, "kernel": k, "valu_wave_instructions": v.get("SQ_INSTS_VALU"), "mfma_busy_cycles": v.get("SQ_VALU_MFMA_BUSY_CYCLES"),
                     "simd_time_valu_issue_frac": v["SQ_ACTIVE_INST_VALU"] / simd_quads,
                     "simd_time_mfma_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / 4.0 / simd_quads,
                     "wave_time_waiting_frac": v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"],
@@ -255,6 +269,17 @@ def cpu_baseline_and_parity(wt, vol, inp, D, n_rays, budget_s=15.0):
     par["sampler_stage_identical_inputs"] = {"samples": int(dz.numel()), "dz_max": float(dz.max()), "dz_over_bin_width_max": float((dz / width.clamp(min=1e-9)).max())}
     ce, _ = FU.oracle_self_sensitivity(full, s256, {k: v[:256] for k, v in ref.items()}, seeds=(1,))
     par["oracle_self_sensitivity_to_2e-6_sdf_noise_color_q50_q90_q99_max"] = [float(torch.quantile(ce.flatten(), x)) for x in (0.5, 0.9, 0.99)] + [float(ce.max())]
+    # the volume build itself (FeatureNet -> compress -> cost volume -> sparse CNN -> scatter) against the oracle's, from the images, at this size
+    t0 = time.time()
+    ov = FU.oracle_volume(wt, inp["sc"], D)
+    par["volume_vs_oracle"] = dict(FU.volume_vs_oracle(vol, ov, D), oracle_seconds=time.time() - t0,
+                                   note="max abs error / max|oracle| per tensor; integer results exact (tests/test_gpu_edges_and_fullsize.py::test_fullsize_volume_vs_oracle)")
+    ov = None
+    # end-to-end mesh agreement: HIP's extraction field vs the oracle's on the 64^3 sub-block of the 256^3 lattice with the most sign changes
+    u = pipeline.extract_mesh(wt, vol, inp["proj"], inp["cam_pos"], 256)[3]
+    mf = FU.mesh_field_vs_oracle(ops, wt, vol, u, 256, 64)
+    par["mesh_sign_flips"] = mf["mesh_sign_flips"]
+    par["mesh_vs_oracle_field"] = mf
     return cpu, par
 
 
@@ -355,6 +380,9 @@ def main():
                                                              "--backend gloo, RCCL refuses duplicate devices).  The number it prints is not a scaling measurement")
     ap.add_argument("--precision", choices=config.PRECISIONS, default=config.PRECISION,
                     help="network kernels: f16x3 (default; split-f16 MFMA, fp32-class accuracy), fp32 (exact fp32 MFMA), bf16 (SDF throughput mode)")
+    ap.add_argument("--ckpt", default=None, help="checkpoint in the reference's format (exp_runner...:514-541); default: seeded stand-in weights, identical on every rank")
+    ap.add_argument("--broadcast-weights", action="store_true", help="with --ckpt: rank 0 reads the file, ONE RCCL broadcast hands the weights to the other ranks "
+                                                                      "(the north star's optional shared-backbone broadcast); default: every rank reads the file")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         reexec_under_torchrun(a.gpus)
@@ -382,7 +410,10 @@ def main():
         ids = [None] * world
         torch.distributed.all_gather_object(ids, (os.uname().nodename, local))
         assert len(set(ids)) == world, f"ranks share a device: {ids}"
-    wt = pipeline.SceneWeights(dev, seed=0, sdf_precision=a.precision, color_precision=a.precision)
+    if a.ckpt:
+        wt = pipeline.SceneWeights.from_checkpoint(dev, a.ckpt, broadcast=a.broadcast_weights)
+    else:
+        wt = pipeline.SceneWeights(dev, seed=0, sdf_precision=a.precision, color_precision=a.precision)
     wt.grid_tables(a.mesh_res)      # per-(network, resolution) tables of the lattice SDF kernel: part of loading the weights, like the operand blobs
     inp = make_inputs(dev, a.views, seed=rank, ray_scale=a.ray_scale)
     # distinct scene per step: scene index = rank + world * step (images resident in HBM before the timed region starts)
@@ -409,9 +440,16 @@ def main():
         if os.environ.get("O2345_BENCH_VERBOSE"):
             st = torch.cuda.memory_stats()
             alloc_log.append((st["num_device_alloc"], st["num_device_free"], round((time.perf_counter() - t0) * 1e3, 1)))
+    t_own = time.perf_counter() - t0                         # this rank's own clock, before it waits for the others
     sharding.barrier(dev)
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
     tm.collect()
+    # per-rank view of the same K steps (a straggler GPU shows up here the first time --gpus N runs on real hardware): gathered as small objects
+    props = torch.cuda.get_device_properties(dev)
+    per_rank = sharding.gather_objects({
+        "rank": rank, "device": f"cuda:{local}", "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")),
+        "host": os.uname().nodename, "ms_per_step_own_clock": t_own / a.steps * 1e3,
+        "step_ms_min_median_max": [float(np.min(s_)), float(np.median(s_)), float(np.max(s_))] if (s_ := [sum(x) for x in zip(tm.acc["volume"], tm.acc["render"], tm.acc["mesh"])]) else None})
     if os.environ.get("O2345_BENCH_VERBOSE"):
         print({k: [round(x, 2) for x in v] for k, v in tm.acc.items()}, file=sys.stderr)
         print("per step (device allocs, frees, host ms since start):", alloc_log, file=sys.stderr)
@@ -438,6 +476,9 @@ def main():
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             **({"shared_gpu_functional_run": True} if a.share_gpu else {}),
+            **({"rccl_ranks": world, "backend": torch.distributed.get_backend(), "per_rank": per_rank,
+                "weights": ("checkpoint, broadcast from rank 0" if a.broadcast_weights else "checkpoint, read by every rank") if a.ckpt else "seeded stand-ins, built per rank"}
+               if world > 1 else {}),
             "config": {"workload": f"BASELINE config 2: 1 scene/GPU/step ({'the same scene' if a.same_scene else 'a different seeded scene'} every step), "
                                    f"{a.views} views 256x256, {a.vol}^3 volume, "
                                    f"{n_rays} rays (64+64 samples), mesh grid {a.mesh_res}^3; whole scene pass per step",
@@ -449,8 +490,9 @@ def main():
             "occupied_points": nvp, "sampled_points": npts,
             # dominant kernel of a step = the colour network: ALGORITHMIC FLOP (38,544 per (point, view)) x occupied
             # points x views / HIP-event time of that launch, against the dense MFMA peak of the type the matrix pipe runs in
-            "roofline": dict(rl["color"], traffic=pmc_traffic("k_color_mfma"),
-                             traffic_source=PMC_FILE + " (bytes, 2*FETCH_SIZE+WRITE_SIZE)", issue_model=pmc_issue_model("k_color_mfma", kt["color_ms"])),
+            "roofline": dict(rl["color"], traffic=pmc_traffic(COLOR_KERNEL_PREFIX),
+                             traffic_source=(f"{PMC_FILE} (bytes, 2*FETCH_SIZE+WRITE_SIZE; collected on these kernel sources)" if PMC_DATA is not None else PMC_STALE),
+                             issue_model=pmc_issue_model(COLOR_KERNEL_PREFIX, kt["color_ms"])),
             "roofline_sdf": rl["sdf"], "roofline_sdf_grad": rl["sdf_grad"],
             "roofline_costvol": {"kernel": "k_costvol_gather<16>", "bound": "hbm", "achieved": cv_bytes / (kt["costvol_gather_ms"] * 1e-3) / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cv_bytes / (kt["costvol_gather_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,

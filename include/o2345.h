@@ -178,8 +178,9 @@ int o2345_ray_upsample(const float* rays_o, const float* rays_d, int R, const fl
                        float inv_s, const float* maskvol, int D, float* wbuf, int n_imp, float* new_z, float* new_pts,
                        float* new_sdf, int32_t* list, int32_t* count_dev, void* stream);
 int o2345_ray_merge(int R, float* z, float* sdf, int S, float* new_z, float* new_sdf, int n_new, void* stream);
-/* finalize: mid points, section lengths, occupancy of the mid points and the list of occupied slots; the reference's defaults (sdf = 100, grad = rgb = 0)
- * are written for UNOCCUPIED points only -- the caller evaluates every list entry (as o2345_render_rays does), which overwrites the others */
+/* finalize: mid points, section lengths, occupancy of the mid points and the list of occupied slots; every slot of sdf / grad / rgb receives the
+ * reference's defaults (sdf = 100, grad = rgb = 0; models/sparse_neus_renderer.py:231), occupied or not -- a caller may evaluate any part of the list.
+ * (o2345_render_rays, which evaluates every list entry, uses an internal variant that skips the occupied slots.) */
 int o2345_ray_finalize(const float* rays_o, const float* rays_d, int R, const float* z, int S, float sample_dist,
                        const float* maskvol, int D, float* mid_z, float* dists, float* pts, float* pm, float* sdf,
                        float* grad, float* rgb, int32_t* list, int32_t* count_dev, void* stream);

@@ -14,6 +14,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 EXTRA_FLAGS = {name: ["-fno-honor-nans"] for name in ("sdf_mlp.hip", "sdf_mlp_bf16.hip", "sdf_mlp_x3.hip", "color_mfma.hip", "color_pts.hip")}
 
 
+def sources_sha():
+    """sha256 (first 16 hex digits) over the kernel sources and headers (csrc/*, sorted by name): what a profile / counter file was measured on.
+    tools/summarize_rocprof.py stamps it into every profiles/*.json; bench.py prints counter-derived numbers only when it matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True

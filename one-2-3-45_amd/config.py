@@ -9,7 +9,9 @@
 * ``"bf16"``  bf16 operands for the wide layers of the SDF network only (BASELINE config 2's "bf16 SDF MLP" throughput mode;
   1e-3-level SDF error); the colour network runs in the f16x3 form.
 
-Everything else (cost volume, sparse convolutions, sampling, compositing, marching cubes) is precision-independent."""
+The convolutions (FeatureNet, compress layer, sparse cost-regularisation network) follow the COLOUR mode: split-f16 on the matrix cores by
+default, fp32 VALU kernels in ``"fp32"`` mode -- per object when a mode is handed to ``pipeline.SceneWeights`` / ``featurenet.set_precision``,
+else this global one.  Cost-volume gather, sampling, compositing and marching cubes are precision-independent (fp32 / fp64 / integer)."""
 import os
 
 PRECISIONS = ("f16x3", "fp32", "bf16")

@@ -402,6 +402,7 @@ int o2345_pack_color_maps(const float* feat_nchw, const float* color_nchw, int V
 int o2345_view_count_unlisted(const float* pts, long long n, const float* skip_if_positive, const float* maskvol, int D, const float* proj, int V,
                               int H, int W, uint8_t* out, void* stream) {
     O2345_REQUIRE(pts && maskvol && proj && out, "view_count: null pointer");
+    O2345_REQUIRE(V >= 1 && V <= 255, "view_count: V must be in [1,255] (counts are stored as uint8; got %d)", V);
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_view_count, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, n, maskvol, D, proj, V, H, W, out, skip_if_positive);
     return check_launch("view_count");

@@ -43,6 +43,8 @@ __global__ __launch_bounds__(768) void k_color_mfma(ColorMArgs a) {
     const long long n = a.n_dev ? (long long)*a.n_dev : a.n;
     const float m1 = X3 ? opaque_minus_one() : -1.f;
     const float s_abs = fabsf(lds[TAIL + CM_S]) * LOG2E;
+    const int base_prio = (a.sched & 1) ? (wave >> 2) : 0;          // waves w, w + 4, w + 8 share a SIMD (cyclic SIMD assignment)
+    if (a.sched & 1) set_wave_prio(base_prio);
     const TileSched ts = tile_schedule(n, PPT, wave, nwave);
     for (long long tile = ts.first; tile < ts.end; tile += ts.stride) {
         const long long t0 = tile * PPT;
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(768) void k_color_mfma(ColorMArgs a) {
         float rf[32];
 #pragma unroll
         for (int c = 0; c < 32; ++c) rf[c] = 0.f;
+        if (a.sched & 2) set_wave_prio(3);
         {
             const Taps2D tp = bilinear_taps(gx, gy, a.H, a.W_img);
             const float4* img = reinterpret_cast<const float4*>(a.cmaps + (size_t)vv * a.H * a.W_img * 64) + 8 * h;
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(768) void k_color_mfma(ColorMArgs a) {
                     }
                 }
         }
+        if (a.sched & 2) set_wave_prio(base_prio);
         const float rgb0 = rf[0], rgb1 = rf[1], rgb2 = rf[2];      // log2(e) * colours (meaningful in half 0), before the direction feature
         // ---- ray direction difference ------------------------------------------------------------------------------------------
         float rd[4];
@@ -298,7 +302,7 @@ static int color_mfma_launch(bool x3, const float* blob, const float* vol_cl, co
                              const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream) {
     O2345_REQUIRE(blob && vol_cl && maskvol && cmaps && proj && cam_pos && pts && out_rgb, "color_points_mfma: null pointer");
     O2345_REQUIRE((query_cam != nullptr) != (normals != nullptr), "color_points_mfma: give exactly one of query_cam / normals");
-    O2345_REQUIRE(V >= 1, "color_points_mfma: V must be >= 1 (got %d)", V);
+    O2345_REQUIRE(V >= 1 && V <= 255, "color_points_mfma: V must be in [1,255] (valid-view counts are stored as uint8; got %d)", V);
     if (n <= 0 && !n_dev) return 0;
     {
         // Two kernels compute the same function: k_color_mfma (columns = (point, view) pairs, view count padded to a
@@ -316,6 +320,7 @@ static int color_mfma_launch(bool x3, const float* blob, const float* vol_cl, co
                                     out_rgb, out_nviews, stream);
     }
     ColorMArgs a{blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews};
+    a.sched = color_sched_mode();
     int G = 4;
     while (G < V) G <<= 1;
     const int n_cu = cu_count();
@@ -350,7 +355,7 @@ int o2345_project_features(const float* vol_cl, const float* maskvol, int D, con
                            float* ray_diff, float* mask, void* stream) {
     O2345_REQUIRE(vol_cl && maskvol && cmaps && proj && cam_pos && pts && geometry_feat && rgb_feat && ray_diff && mask, "project_features: null pointer");
     O2345_REQUIRE((query_cam != nullptr) != (normals != nullptr), "project_features: give exactly one of query_cam / normals");
-    O2345_REQUIRE(V >= 1 && P >= 0 && P * V < (1ll << 33), "project_features: bad sizes");
+    O2345_REQUIRE(V >= 1 && V <= 255 && P >= 0 && P * V < (1ll << 33), "project_features: bad sizes (V in [1,255])");
     if (P == 0) return 0;
     return project_features_launch(vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, P, query_cam, normals, geometry_feat, rgb_feat, ray_diff, mask, stream);
 }
@@ -361,7 +366,7 @@ int o2345_project_features(const float* vol_cl, const float* maskvol, int D, con
 int o2345_color_from_features(const float* blob, int x3, const float* geometry_feat, const float* rgb_feat, const float* ray_diff, const float* mask,
                               int V, long long P, float* out_rgb, uint8_t* out_nviews, void* stream) {
     O2345_REQUIRE(blob && geometry_feat && rgb_feat && ray_diff && mask && out_rgb, "color_from_features: null pointer");
-    O2345_REQUIRE(V >= 1 && P >= 0, "color_from_features: bad sizes");
+    O2345_REQUIRE(V >= 1 && V <= 255 && P >= 0, "color_from_features: bad sizes (V in [1,255]: valid-view counts are stored as uint8)");
     if (P == 0) return 0;
     return color_feats_launch(x3, blob, geometry_feat, rgb_feat, ray_diff, mask, V, P, out_rgb, out_nviews, stream);
 }

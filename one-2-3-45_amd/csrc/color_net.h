@@ -63,7 +63,24 @@ struct ColorMArgs {
     const float* f_rgb;       // [V,P,59]  colours (3) | features (56)
     const float* f_rdiff;     // [V,P,4]
     const float* f_mask;      // [V,P]     non-zero = the projection is valid
+    int sched;                // wave-scheduling knobs (O2345_COLOR_SCHED, A/B runs): bit 0 = static priority by SIMD slot (the k-th wave of a SIMD
+                              // runs at priority k), bit 1 = priority 3 while a wave issues its pixel gathers
 };
+
+inline int color_sched_mode() {
+    const char* e = getenv("O2345_COLOR_SCHED");
+    return e ? atoi(e) : 0;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ void set_wave_prio(int p) {       // s_setprio takes an immediate
+    switch (p) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+#endif
 
 // ELU is evaluated ~150 times per lane and tile (a quarter of the kernel's VALU instructions), so the whole network runs in a
 // log2(e)-scaled domain: every layer that feeds an ELU produces y = log2(e) * x (its weights / bias are pre-scaled on the host,

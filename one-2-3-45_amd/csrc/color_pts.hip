@@ -129,7 +129,13 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
     const float m1 = X3 ? opaque_minus_one() : -1.f;
     const float s_abs = fabsf(lds[L_S]) * LOG2E;
     const int V = a.V;
-    const TileSched ts = tile_schedule(n, 32, wave, nwave);
+    const bool skip_views = V <= 64 && !(a.sched & 4);              // bit 2 of O2345_COLOR_SCHED: evaluate every view (A/B runs)
+    const int base_prio = (a.sched & 1) ? (wave >> 2) : 0;          // waves w and w + 4 share a SIMD (cyclic SIMD assignment)
+    if (a.sched & 1) set_wave_prio(base_prio);
+    // bit 3 of O2345_COLOR_SCHED: block-interleaved tiles instead of one contiguous eighth of the list per XCD (A/B: with view skipping the
+    // cost of a tile depends on where its rays look, and a contiguous eighth of the image is not an eighth of the work)
+    const TileSched ts = (a.sched & 8) ? TileSched{(long long)blockIdx.x * nwave + wave, (n + 31) / 32, (long long)gridDim.x * nwave}
+                                       : tile_schedule(n, 32, wave, nwave);
     for (long long tile = ts.first; tile < ts.end; tile += ts.stride) {
         const long long i = tile * 32 + j;
         const bool live = i < n;
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
         // ---- pass A: weighted mean / variance over the views of this half's 32 pixel floats ----------------------------------------
         // Welford update with the un-normalised weights raw_v = (e_v - emin) m_v: mean_w = sum(raw x)/sum(raw), M2 = sum raw (x - mean_w)^2
         float wsum = 0.f, nvis = 0.f;
+        unsigned long long active = 0ull;            // wave-uniform: views that see at least one point of the tile
         {
             float mean[32], m2[32];
 #pragma unroll
@@ -200,9 +207,18 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
 #pragma unroll 1
             for (int v = 0; v < V; ++v) {
                 const ViewGeom g = FEATS ? feat_geom(a, v, slot, s_abs) : view_geom(a, v, px, py, pz, qx, qy, qz, gvalid, s_abs);
+                // A view that sees NONE of the tile's 32 points (wave-uniform test) contributes exactly nothing to this pass: raw = 0 leaves wsum,
+                // nvis, mean and M2 bit-unchanged.  Points of a tile are neighbours (32 adjacent rays at one sample index), so visibility is
+                // coherent: at BASELINE config 2 a point is seen by 4.8 of the 8 views on average and 37 % of the (tile, view) pairs are skipped.
+                if (skip_views && __builtin_amdgcn_ballot_w64(g.m != 0.f) == 0ull) continue;
+                active |= 1ull << (v & 63);
                 float rf[32];
                 if constexpr (FEATS) load_feats(a, h, v, slot, rf);
-                else gather_now(a, h, v, g, rf);
+                else {
+                    if (a.sched & 2) set_wave_prio(3);
+                    gather_now(a, h, v, g, rf);
+                    if (a.sched & 2) set_wave_prio(base_prio);
+                }
                 {
                     float d16[8];
                     direction_layer1<X3>(lds, TAIL, lane, h, g, m1, d16);
@@ -239,13 +255,22 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
         else cm_run<2, 72, 72>(sh, lds + L_AS + lane, 0, bs);
         // ---- pass B: per view network, online softmax over the views ------------------------------------------------------------------
         float smax = -INFINITY, ssum = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        // A masked view enters the softmax with score -1e9: its blending weight is exp2(-1e9 - max) = 0 EXACTLY as soon as the point has one
+        // visible view, whatever the order.  Only a point with NO visible view blends the masked views (uniformly): if the tile holds such a
+        // point, every view is evaluated as before; otherwise the views that see none of the tile's points are skipped -- bit-identical results.
+        const bool skip_b = skip_views && __builtin_amdgcn_ballot_w64(live && nvis == 0.f) == 0ull;
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
+            if (skip_b && !((active >> (v & 63)) & 1ull)) continue;
             const ViewGeom g = FEATS ? feat_geom(a, v, slot, s_abs) : view_geom(a, v, px, py, pz, qx, qy, qz, gvalid, s_abs);
             const float m = g.m;
             float rf[32];
             if constexpr (FEATS) load_feats(a, h, v, slot, rf);
-            else gather_now(a, h, v, g, rf);
+            else {
+                if (a.sched & 2) set_wave_prio(3);
+                gather_now(a, h, v, g, rf);
+                if (a.sched & 2) set_wave_prio(base_prio);
+            }
             const float rgb0 = rf[0], rgb1 = rf[1], rgb2 = rf[2];   // log2(e) * colours (meaningful in half 0), before the direction feature
             {
                 float d16[8];
@@ -355,6 +380,7 @@ int color_pts_launch(int x3, const float* blob, const float* vol_cl, const float
                            const float* cam_pos, int V, int H, int W, const float* pts, const int32_t* index, const int32_t* n_dev,
                            long long n, const float* query_cam, const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream) {
     ColorMArgs a{blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews};
+    a.sched = color_sched_mode();
     const int n_cu = cu_count();
     const int threads = CP_THREADS;
     const long long per_block = (long long)(threads / 64) * 32;

@@ -1,5 +1,5 @@
 // Feature-pyramid glue of FeatureNet as two fused HIP kernels (models/featurenet.py:68-91,
-// models/trainer_generic.py:1104-1125).  The convolutions stay on MIOpen; what is fused is everything between them:
+// models/trainer_generic.py:1104-1125).  The convolutions are csrc/convnet.hip; what is fused here is everything between them:
 //
 //   k_fpn_level     f_out = lateral 1x1 conv (C_in -> 32, + bias) of the finer map + bilinear x2 up-sampling (align_corners = True) of the
 //                   coarser map                                   (featurenet.py:73-76, 85-86: `_upsample_add(feat, lat(conv))`)

@@ -10,9 +10,13 @@ namespace o2345 {
 // z >= 0 is clamped to >= 1e-6, negative z untouched; valid = |gx|<=1 & |gy|<=1 & z>0.
 O2345_HD void project_voxel(const float* __restrict__ P, float wx, float wy, float wz, int H, int W,
                             float& gx, float& gy, bool& valid) {
-    float x = P[0] * wx + P[1] * wy + P[2] * wz + P[3];
-    float y = P[4] * wx + P[5] * wy + P[6] * wz + P[7];
-    float z = P[8] * wx + P[9] * wy + P[10] * wz + P[11];
+    // The reference forms these with a GEMM over k (proj_batch @ rs_grid, ops/back_project.py:52): BLAS kernels (MKL on the host, cuBLAS / rocBLAS on a GPU)
+    // accumulate a tiny-K product as ONE FMA chain in k order, acc = fma(a_k, b_k, acc) -- which is also what ATen's CPU matmul does (checked on
+    // 16.7 M voxels x 8 views: bit-identical to this chain, while the mul / add sequence differs in the last bit of ~15 % of the values and flips the
+    // frustum test of 3 voxels in 256^3).  The translation enters with b_3 = 1, so the last step is an exact add.
+    float x = fmaf(P[2], wz, fmaf(P[1], wy, P[0] * wx)) + P[3];
+    float y = fmaf(P[6], wz, fmaf(P[5], wy, P[4] * wx)) + P[7];
+    float z = fmaf(P[10], wz, fmaf(P[9], wy, P[8] * wx)) + P[11];
     if (z >= 0.f) z = fmaxf(z, 1e-6f);
     gx = 2.f * (x / z) / (float)(W - 1) - 1.f;
     gy = 2.f * (y / z) / (float)(H - 1) - 1.f;

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void k_ray_finalize(RayGeom g, const float* __
                                                       const float* __restrict__ maskvol, int D, float* __restrict__ mid_z,
                                                       float* __restrict__ dists, float* __restrict__ pts,
                                                       float* __restrict__ pm, float* __restrict__ sdf, float* __restrict__ grad,
-                                                      float* __restrict__ rgb, int* __restrict__ list, int* __restrict__ count) {
+                                                      float* __restrict__ rgb, int* __restrict__ list, int* __restrict__ count,
+                                                      int defaults_everywhere) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     const bool live = r < g.R;
     ValidBits bits{};
@@ -118,9 +119,10 @@ __global__ __launch_bounds__(256) void k_ray_finalize(RayGeom g, const float* __
             dists[p] = d; mid_z[p] = mz; pm[p] = m;
             pts[3 * p] = x; pts[3 * p + 1] = y; pts[3 * p + 2] = w;
             if (m > 0.f) { bits.w[s >> 5] |= 1u << (s & 31); ++cnt; }
-            else {
-                // the reference's defaults (:231: sdf = 100, gradients = colours = 0).  Occupied points are ALWAYS overwritten by the network kernels that
-                // consume the list (o2345_render_rays evaluates every list entry), so only unoccupied points need them: 28 bytes less per occupied point
+            if (!(m > 0.f) || defaults_everywhere) {
+                // the reference's defaults (:231: sdf = 100, gradients = colours = 0).  Inside o2345_render_rays occupied points are ALWAYS overwritten by the
+                // network kernels that consume the list (every list entry is evaluated), so only unoccupied points need them there: 28 bytes less per
+                // occupied point.  The public stage entry initialises every slot (a caller may evaluate only part of the list).
                 sdf[p] = 100.f;
                 grad[3 * p] = 0.f; grad[3 * p + 1] = 0.f; grad[3 * p + 2] = 0.f;
                 rgb[3 * p] = 0.f; rgb[3 * p + 1] = 0.f; rgb[3 * p + 2] = 0.f;
@@ -201,16 +203,23 @@ int o2345_ray_merge(int R, float* z, float* sdf, int S, float* new_z, float* new
     return check_launch("ray_merge");
 }
 
-int o2345_ray_finalize(const float* rays_o, const float* rays_d, int R, const float* z, int S, float sample_dist,
-                       const float* maskvol, int D, float* mid_z, float* dists, float* pts, float* pm, float* sdf,
-                       float* grad, float* rgb, int32_t* list, int32_t* count_dev, void* stream) {
+static int ray_finalize_launch(const float* rays_o, const float* rays_d, int R, const float* z, int S, float sample_dist,
+                               const float* maskvol, int D, float* mid_z, float* dists, float* pts, float* pm, float* sdf,
+                               float* grad, float* rgb, int32_t* list, int32_t* count_dev, void* stream, int defaults_everywhere) {
     O2345_REQUIRE(rays_o && rays_d && z && maskvol && mid_z && dists && pts && pm && sdf && grad && rgb && list && count_dev, "ray_finalize: null pointer");
     O2345_REQUIRE(S >= 1 && S <= 256, "ray_finalize: at most 256 samples per ray (got %d)", S);
     RayGeom g{rays_o, rays_d, R};
     hipStream_t s = (hipStream_t)stream;
     O2345_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_ray_finalize, dim3(cdiv(R, 256)), dim3(256), 0, s, g, z, S, sample_dist, maskvol, D, mid_z, dists, pts, pm, sdf, grad, rgb, list, count_dev);
+    hipLaunchKernelGGL(k_ray_finalize, dim3(cdiv(R, 256)), dim3(256), 0, s, g, z, S, sample_dist, maskvol, D, mid_z, dists, pts, pm, sdf, grad, rgb, list, count_dev,
+                       defaults_everywhere);
     return check_launch("ray_finalize");
+}
+
+int o2345_ray_finalize(const float* rays_o, const float* rays_d, int R, const float* z, int S, float sample_dist,
+                       const float* maskvol, int D, float* mid_z, float* dists, float* pts, float* pm, float* sdf,
+                       float* grad, float* rgb, int32_t* list, int32_t* count_dev, void* stream) {
+    return ray_finalize_launch(rays_o, rays_d, R, z, S, sample_dist, maskvol, D, mid_z, dists, pts, pm, sdf, grad, rgb, list, count_dev, stream, 1);
 }
 
 int o2345_ray_composite(const float* rays_o, const float* rays_d, int R, int S, const float* mid_z, const float* dists,
@@ -288,7 +297,7 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     }
     const float sample_dist = (io->far - io->near) / (float)NS;
     float* fpts = pts;   // reuse
-    if ((rc = o2345_ray_finalize(io->rays_o, io->rays_d, R, z, (int)S, sample_dist, io->maskvol, io->D, io->mid_z, io->dists, fpts, io->pm, io->sdf, io->grad, io->rgb, list, count, stream))) return rc;
+    if ((rc = ray_finalize_launch(io->rays_o, io->rays_d, R, z, (int)S, sample_dist, io->maskvol, io->D, io->mid_z, io->dists, fpts, io->pm, io->sdf, io->grad, io->rgb, list, count, stream, 0))) return rc;
     hipLaunchKernelGGL(k_quirk_first100, dim3(1), dim3(128), 0, s, count, list, R, (int)S);
     if ((rc = sdf_eval(2, fpts, list, count, 0, io->sdf, io->grad))) return rc;
     // valid-view counts (feed the per-ray colour mask): the colour kernels write them for the points they evaluate (the occupied ones, 88 % at

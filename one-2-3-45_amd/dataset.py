@@ -60,7 +60,10 @@ def normalised_pose(K4, w2c, scale_mat):
 
 
 class SceneFolder:
-    """``BlenderPerView(root_dir, split, ..., specific_dataset_name=name)`` for split 'val' / 'export_mesh': one scene per folder."""
+    """``BlenderPerView(root_dir, split, ..., specific_dataset_name=name)`` for split 'val' / 'export_mesh': one scene per folder.
+    Difference from the reference, split 'export_mesh' only: the reference draws N_rays RANDOM rays for every split whose name contains neither
+    'val' nor 'test' (One2345_eval_new_data.py:354-372), which export_mesh_step never reads; here every split carries the full val ray grid
+    (deterministic; a caller that wants the reference's random subset indexes it)."""
 
     def __init__(self, root_dir, split="val", img_wh=(256, 256), vol_dims=(128, 128, 128), specific_dataset_name="", clean_image=False, **_unused):
         if split not in ("val", "export_mesh", "test"):

@@ -8,14 +8,32 @@ import torch.nn as nn
 from . import ops
 
 
-def packed_weight(conv):
-    """The kernel packing of an nn.Conv2d's weight, cached ON the module that owns the parameter (re-packed when the parameter object, its
-    version or its storage changes -- load_state_dict, .to(device), an optimiser step)."""
+def packed_weight(conv, precision=None):
+    """The kernel packing of an nn.Conv2d's weight for the numerical mode ``precision`` (None = the global mode), cached ON the module that owns
+    the parameter.  Re-packed when the parameter object, its version counter, its storage or the mode changes -- load_state_dict, .to(device), an
+    optimiser step, any in-place op on the Parameter.  Writes through ``.data`` (``w.data.copy_(...)``, EMA / weight-surgery code) do NOT bump the
+    version counter: call ``invalidate_packed(module)`` after such an update."""
     w = conv.weight
-    key = (id(w), w._version, w.data_ptr(), str(w.device), ops.conv_x3())
+    key = (id(w), w._version, w.data_ptr(), str(w.device), ops.conv_x3(precision))
     if getattr(conv, "_o2345_packed_key", None) != key:
-        conv._o2345_packed, conv._o2345_packed_key = ops.conv2d_pack(w.detach()), key
+        conv._o2345_packed, conv._o2345_packed_key = ops.conv2d_pack(w.detach(), precision), key
     return conv._o2345_packed
+
+
+def invalidate_packed(module):
+    """Drop every cached weight packing below ``module`` (after parameter updates through ``.data``, which no version counter sees)."""
+    for m in module.modules():
+        for attr in ("_o2345_packed_key", "_blob_key"):
+            if hasattr(m, attr):
+                setattr(m, attr, None)
+
+
+def set_precision(module, precision):
+    """Numerical mode of every convolution below ``module`` ("f16x3" | "fp32" | None = follow the global O2345_PRECISION)."""
+    for m in module.modules():
+        if isinstance(m, (ConvBnReLU, FeatureNet)):
+            m.precision = precision
+    return module
 
 
 class InPlaceABN(nn.Module):
@@ -54,13 +72,15 @@ class ConvBnReLU(nn.Module):
             raise NotImplementedError("o2345 ConvBnReLU: padding = kernel // 2 (as everywhere in the reference)")
         self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False)
         self.bn = InPlaceABN(cout)
+        self.precision = None                             # None = the global mode; SceneWeights sets its own (set_precision)
 
     def raw(self, x, in_scale_shift=None, nhwc_offset=None):
         """-> (raw conv output, this layer's ABN (scale | shift)); ``in_scale_shift``: x is itself a raw output to be activated on load;
         ``nhwc_offset``: x is a channel-last map whose channels nhwc_offset .. + cin are the input."""
         bn = self.bn                                      # ops.conv2d raises for CPU tensors: there is no CPU fallback
         return ops.conv2d(x.contiguous().float(), self.conv.weight.detach(), None, self.conv.stride[0], in_scale_shift, bn.slope,
-                          bn=(bn.weight.detach(), bn.bias.detach(), bn.eps, bn.abs_gamma), packed=packed_weight(self.conv), nhwc_offset=nhwc_offset)
+                          bn=(bn.weight.detach(), bn.bias.detach(), bn.eps, bn.abs_gamma), packed=packed_weight(self.conv, self.precision),
+                          precision=self.precision, nhwc_offset=nhwc_offset)
 
     def forward(self, x):
         r, ss = self.raw(x)
@@ -84,6 +104,7 @@ class FeatureNet(nn.Module):
         self.lat0 = nn.Conv2d(8, 32, 1)
         self.smooth1 = nn.Conv2d(32, 16, 3, padding=1)
         self.smooth0 = nn.Conv2d(32, 8, 3, padding=1)
+        self.precision = None
 
     def forward(self, x):
         """[V,3,H,W] -> [f2 (32 @ H/4), smooth1 (16 @ H/2), smooth0 (8 @ H)] (featurenet.py:68-91).  25 HIP launches, no library call: every
@@ -96,12 +117,13 @@ class FeatureNet(nn.Module):
             raws.append((r, ss))
         (c0, ss0), (c1, ss1), (c2, ss2) = raws
         slope = self.conv0[0].bn.slope
-        f2, _ = ops.conv2d(c2, self.toplayer.weight.detach(), self.toplayer.bias.detach(), 1, ss2, slope, packed=packed_weight(self.toplayer))
+        pr = self.precision
+        f2, _ = ops.conv2d(c2, self.toplayer.weight.detach(), self.toplayer.bias.detach(), 1, ss2, slope, packed=packed_weight(self.toplayer, pr), precision=pr)
         # top-down path: lateral 1x1 convolution + x2 bilinear up-sampling + add, one kernel per level (csrc/featmaps.hip)
         f1 = ops.fpn_level(c1, f2, self.lat1.weight.detach(), self.lat1.bias.detach(), ss1, slope)
         f0 = ops.fpn_level(c0, f1, self.lat0.weight.detach(), self.lat0.bias.detach(), ss0, slope)
-        s1, _ = ops.conv2d(f1, self.smooth1.weight.detach(), self.smooth1.bias.detach(), packed=packed_weight(self.smooth1))
-        s0, _ = ops.conv2d(f0, self.smooth0.weight.detach(), self.smooth0.bias.detach(), packed=packed_weight(self.smooth0))
+        s1, _ = ops.conv2d(f1, self.smooth1.weight.detach(), self.smooth1.bias.detach(), packed=packed_weight(self.smooth1, pr), precision=pr)
+        s0, _ = ops.conv2d(f0, self.smooth0.weight.detach(), self.smooth0.bias.detach(), packed=packed_weight(self.smooth0, pr), precision=pr)
         return [f2, s1, s0]
 
 

@@ -420,8 +420,9 @@ def pack_color_maps(feat_nchw, color_nchw):
 @_on_device
 def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=None, normals=None, index=None, n_dev=None,
                  want_nviews=True, mfma=False):
-    """mfma=False: VALU kernel (blob from weights.pack_color_blob); mfma=True: fp32 matrix-core kernel (pack_color_mfma_blob,
-    V<=32); mfma="x3": the same kernel with split-f16 matrix steps (pack_color_x3_blob)."""
+    """mfma=False: VALU kernel (blob from weights.pack_color_blob, V <= 64); mfma=True: fp32 matrix-core kernels (pack_color_mfma_blob);
+    mfma="x3": the same kernels with split-f16 matrix steps (pack_color_x3_blob).  The matrix-core path takes any view count up to 255
+    (k_color_mfma for powers of two up to 32, k_color_pts otherwise)."""
     V, H, W, _ = cmaps.shape
     P = pts.shape[0]
     n = P if index is None else index.shape[0]
@@ -556,6 +557,21 @@ def ray_upsample(rays_o, rays_d, z, sdf, inv_s, maskvol, D, n_imp):
 
 
 # ---------------------------------------------------------------------------------------------------------- marching cubes
+@_on_device
+def ray_finalize(rays_o, rays_d, z, sample_dist, maskvol, D):
+    """Stage entry point of render_core's head (sparse_neus_renderer.py:204-231): z SAMPLE-MAJOR [S,R] -> dict(mid_z, dists, pm [S,R], pts [S,R,3],
+    sdf [S,R] = 100, grad / rgb [S,R,3] = 0 (the reference's defaults in EVERY slot), list int32 (occupied slots s*R + r, wave-major), count)."""
+    S, R = z.shape
+    dev = z.device
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    o = dict(mid_z=f(S, R), dists=f(S, R), pts=f(S, R, 3), pm=f(S, R), sdf=f(S, R), grad=f(S, R, 3), rgb=f(S, R, 3),
+             list=torch.empty(S * R, dtype=torch.int32, device=dev), count=torch.zeros(1, dtype=torch.int32, device=dev))
+    check(_lib.lib().o2345_ray_finalize(_p(rays_o), _p(rays_d), R, _p(z), S, float(sample_dist), _p(maskvol), int(D), _p(o["mid_z"]), _p(o["dists"]),
+                                        _p(o["pts"]), _p(o["pm"]), _p(o["sdf"]), _p(o["grad"]), _p(o["rgb"]), _p(o["list"], torch.int32),
+                                        _p(o["count"], torch.int32), _stream()), "ray_finalize")
+    return o
+
+
 @_on_device
 def mesh_pack(verts_idx, tris, grid_R, bound_min=(-1.0, -1.0, -1.0), bound_max=(1.0, 1.0, 1.0), scale_mat=None, trans_mat=None, rgb=None):
     """Index-space vertices (fp64 [N,3]) + triangles -> (vertex records uint8 [N,16|12], face records uint8 [M,13]) of a binary PLY;

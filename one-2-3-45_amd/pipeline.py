@@ -7,7 +7,7 @@ import torch.nn.functional as F
 
 from . import config, ops, weights
 from .costreg import CostRegNet
-from .featurenet import ConvBnReLU, FeatureNet, fused_pyramid
+from .featurenet import ConvBnReLU, FeatureNet, fused_pyramid, set_precision
 
 
 def _load_checked(module, sd, what):
@@ -30,8 +30,8 @@ class SceneWeights:
         self.sdf_precision = sdf_precision        # "f16x3" (default) | "fp32" | "bf16": see config.py
         with torch.random.fork_rng(devices=[]):         # seeded stand-in initialisation must not reset the caller's global RNG
             torch.manual_seed(seed)
-            self.featurenet = FeatureNet().to(device)
-            self.compress = ConvBnReLU(56, 16).to(device)
+            self.featurenet = set_precision(FeatureNet().to(device), color_precision)      # 2-D convolutions follow the same mode as the
+            self.compress = set_precision(ConvBnReLU(56, 16).to(device), color_precision)   # sparse ones: strict fp32 means fp32 everywhere
         self.sdfW = sdf or weights.init_sdf_weights(seed)
         self.color_sd = color_sd or weights.init_color_state_dict(seed)
         self.costreg_sd = costreg_sd or weights.init_costreg_state_dict(seed)
@@ -70,6 +70,24 @@ class SceneWeights:
         if featurenet_sd is not None:
             _load_checked(self.featurenet, {k: t(v) for k, v in featurenet_sd.items()}, "pyramid_feature_network")
         return self
+
+
+    @classmethod
+    def from_checkpoint(cls, device, path, broadcast=False):
+        """Every rank builds its weights from ONE checkpoint file in the reference's format (exp_runner_generic_blender_val.py:514-541: keys
+        ``sdf_network_lod0``, ``rendering_network_lod0``, ``variance_network_lod0``, ``pyramid_feature_network``).  Default: each rank reads the file
+        (< 4 MB); ``broadcast=True``: rank 0 reads it and the state dicts reach the other ranks through sharding.broadcast_state_dicts (one RCCL
+        broadcast) -- ``path`` may then be None on the other ranks."""
+        from . import sharding
+        names = ("sdf_network_lod0", "rendering_network_lod0", "variance_network_lod0", "pyramid_feature_network")
+        state = None
+        if not broadcast or sharding.env_rank_world()[0] == 0:
+            ck = torch.load(path, map_location="cpu", weights_only=False)
+            state = {n: {k: v for k, v in ck[n].items() if torch.is_tensor(v) and v.is_floating_point()} for n in names}
+        if broadcast:
+            state = sharding.broadcast_state_dicts(state, device)
+        return cls.from_state_dicts(device, state["sdf_network_lod0"], state["rendering_network_lod0"], state["variance_network_lod0"]["variance"],
+                                    featurenet_sd=state["pyramid_feature_network"])
 
 
 @torch.no_grad()

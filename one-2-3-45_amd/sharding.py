@@ -55,6 +55,45 @@ def sum_over_ranks(value, device=None):
     return float(t.item())
 
 
+def gather_objects(obj):
+    """-> [obj of rank 0, ..., obj of rank world-1] on every rank (tiny python objects: per-rank timings, device ids)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def broadcast_state_dicts(state, device=None, src=0):
+    """The north star's "optional shared-backbone broadcast": rank ``src`` holds ``state`` = {network name: {key: tensor}} (e.g. read from ONE
+    checkpoint file), every other rank passes None and receives an identical copy -- ONE collective on one flat fp32 buffer (< 4 MB for the lod-0
+    model: a single RCCL broadcast over xGMI; gloo in the CPU tests) + one small object broadcast for the layout.  The default is for every rank
+    to read the checkpoint itself; this exists for deployments where only one rank can reach the file."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return state
+    rank = dist.get_rank()
+    layout = None
+    if rank == src:
+        layout = [(n, k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for n, sd in state.items() for k, v in sd.items()]
+    box = [layout]
+    dist.broadcast_object_list(box, src=src)
+    layout = box[0]
+    total = sum(int(torch.Size(shp).numel()) for _, _, shp, _ in layout)
+    dev = _reduce_device(device)
+    if rank == src:
+        flat = torch.cat([state[n][k].detach().reshape(-1).to(torch.float64 if dt == "float64" else torch.float32).float() for n, k, _, dt in layout]).to(dev)
+    else:
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+    dist.broadcast(flat, src=src)
+    flat = flat.cpu()
+    out, o = {}, 0
+    for n, k, shp, dt in layout:
+        cnt = int(torch.Size(shp).numel())
+        out.setdefault(n, {})[k] = flat[o:o + cnt].reshape(shp).to(getattr(torch, dt)).clone()
+        o += cnt
+    return out
+
+
 def shutdown():
     if dist.is_initialized():
         dist.barrier()

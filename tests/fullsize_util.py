@@ -190,3 +190,77 @@ def oracle_self_sensitivity(full, sel, ref, sigma=2e-6, seeds=(1, 2, 3)):
         ce.append((r["color_fine"] - ref["color_fine"]).abs().max(1).values)
         de.append((r["depth"] - ref["depth"]).abs()[:, 0])
     return torch.stack(ce), torch.stack(de)
+
+
+# ------------------------------------------------------------------------------------------------ volume build / mesh field vs the oracle
+def oracle_weight_dicts(wt):
+    """Reference-format state dicts of a pipeline.SceneWeights for the oracle's FeatureNet / compress layer / sparse CNN."""
+    from scene_util import costreg_oracle_weights
+    fsd = {k: v.detach().cpu() for k, v in wt.featurenet.state_dict().items()}
+    csd = {k: v.detach().cpu() for k, v in wt.compress.state_dict().items()}
+    return fsd, csd, costreg_oracle_weights(wt.costreg_sd)
+
+
+@torch.no_grad()
+def oracle_volume(wt, sc, D):
+    """The ORACLE's own get_conditional_volume from the IMAGES (FeatureNet -> fused pyramid -> compress layer -> back-projection + aggregation ->
+    sparse CNN -> dense scatter; oracle/recon.py:conditional_volume).  ~30 GFLOP at BASELINE config 2: tens of seconds on the host."""
+    fsd, csd, cw = oracle_weight_dicts(wt)
+    return O.conditional_volume(torch.from_numpy(sc["images"]), fsd, csd, cw, torch.from_numpy(sc["affine_mats"]), [D, D, D], 2.0 / (D - 1),
+                                torch.from_numpy(sc["partial_vol_origin"]))
+
+
+def _relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+
+
+def volume_vs_oracle(vol, ov, D):
+    """HIP volume build (pipeline.build_volume dict) vs oracle_volume(): integer results as booleans, fp32 tensors as max abs error / max|oracle|."""
+    return {"kept_voxels": int(vol["coords"].shape[0]), "kept_set_exact": bool(torch.equal(vol["coords"].cpu(), ov["coords"])),
+            "view_counts_exact": bool(torch.equal(vol["cnt"].cpu().long().view(-1), ov["cnt"].long().view(-1))),
+            "mask_exact": bool(torch.equal(vol["maskvol"].view(D, D, D).cpu(), ov["mask"][0, 0])),
+            "fused_pyramid": _relerr(vol["cmaps"][..., 3:59].permute(0, 3, 1, 2), ov["fmaps"]),
+            "compressed_maps": _relerr(vol["feats_nhwc"].permute(0, 3, 1, 2), ov["feats16"]),
+            "cost_volume_rows": _relerr(vol["rows"], ov["rows"]), "sparse_cnn_rows": _relerr(vol["rows16"], ov["rows16"]),
+            "dense_volume": _relerr(vol["vol_cl"].permute(3, 0, 1, 2)[None], ov["dense"])}
+
+
+@torch.no_grad()
+def mesh_field_vs_oracle(ops, wt, vol, u, R=256, B=64):
+    """End-to-end mesh agreement on the B^3 sub-block of the R^3 extraction lattice with the most sign changes: HIP's u (the lattice kernel) vs the
+    oracle's extract_fields (sparse_neus_renderer.py:881-905, u = -sdf on linspace(-1,1,R)^3); sign disagreements, IoU of the inside sets, and the
+    two meshes of the block (HIP marching cubes on HIP's u, oracle marching cubes on the oracle's u)."""
+    from oracle import mc as omc
+    ins = (u > 0)
+    chg = (ins[1:] != ins[:-1]).float()
+    best, origin = -1.0, None
+    for x0 in range(0, R - B + 1, 32):
+        for y0 in range(0, R - B + 1, 32):
+            for z0 in range(0, R - B + 1, 32):
+                c = float(chg[x0:x0 + B - 1, y0:y0 + B, z0:z0 + B].sum())
+                if c > best:
+                    best, origin = c, (x0, y0, z0)
+    x0, y0, z0 = origin
+    lin = torch.linspace(-1, 1, R)
+    gx, gy, gz = torch.meshgrid(lin[x0:x0 + B], lin[y0:y0 + B], lin[z0:z0 + B], indexing="ij")
+    pts = torch.stack([gx, gy, gz], -1).reshape(-1, 3)
+    dense = vol["vol_cl"].permute(3, 0, 1, 2).contiguous().cpu()
+    W = {k: torch.from_numpy(np.asarray(v)) for k, v in wt.sdfW.items()}
+    uo = torch.cat([-O.sdf(pts[s:s + (1 << 16)], dense, W)[0][:, 0] for s in range(0, pts.shape[0], 1 << 16)]).view(B, B, B)
+    uh = u[x0:x0 + B, y0:y0 + B, z0:z0 + B].cpu()
+    flips = (uh > 0) != (uo > 0)
+    nflip = int(flips.sum())
+    inter, union = int(((uh > 0) & (uo > 0)).sum()), int(((uh > 0) | (uo > 0)).sum())
+    vh, th = ops.marching_cubes(uh.to(u.device).contiguous(), 0.0)
+    vo, to = omc.marching_cubes(uo.numpy(), 0.0)
+    res = {"block_origin": list(origin), "block": B, "grid": R, "sign_changes_in_block": int(best), "field_err_max": float((uh - uo).abs().max()),
+           "field_scale": float(uo.abs().max()), "mesh_sign_flips": nflip, "flipped_nodes": torch.nonzero(flips)[:20].tolist(),
+           "abs_u_at_flips_max": float(uo[flips].abs().max()) if nflip else 0.0, "inside_nodes_union": union, "iou": inter / max(1, union),
+           "hip_mesh": [int(vh.shape[0]), int(th.shape[0])], "oracle_mesh": [int(vo.shape[0]), int(to.shape[0])]}
+    if nflip == 0 and th.shape[0] == to.shape[0] and vh.shape[0] == vo.shape[0]:
+        res["triangles_identical"] = bool(np.array_equal(th.cpu().numpy(), to))
+        d = np.abs(vh.cpu().numpy() - vo).max(1)
+        res["vertex_shift_max_mean_cells"] = [float(d.max()), float(d.mean())]
+    return res

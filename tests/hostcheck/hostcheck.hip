@@ -33,6 +33,17 @@ int hc_costvol(const float* feats_nhwc, const float* proj, int V, int H, int W, 
     return n;
 }
 
+// visible-view counts of every voxel of a dx x dy x dz lattice (the integer result that decides the kept-voxel set)
+void hc_visible_views(const float* proj, int V, int H, int W, int dx, int dy, int dz, float vs, const float* origin, uint8_t* cnt) {
+    VolGeom g{dx, dy, dz, vs, origin[0], origin[1], origin[2]};
+    const long long nvox = (long long)dx * dy * dz;
+    for (long long v = 0; v < nvox; ++v) {
+        int x, y, z;
+        voxel_xyz(v, g, x, y, z);
+        cnt[v] = (uint8_t)visible_views(proj, V, H, W, g, x, y, z);
+    }
+}
+
 void hc_trilinear_ref(const float* vol_cl, int D, const float* pts, int P, float* out /*[P,16]*/) {
     for (int p = 0; p < P; ++p) {
         Taps3D t = trilinear_ref_taps(pts[3 * p], pts[3 * p + 1], pts[3 * p + 2], D);

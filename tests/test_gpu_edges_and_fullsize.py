@@ -314,43 +314,22 @@ def test_fullsize_numerical_forms_agree(full):
 
 
 # ------------------------------------------------------------------------------- oracle parity of the VOLUME BUILD at the benchmarked size
-def _oracle_weight_dicts(wt):
-    from scene_util import costreg_oracle_weights
-    fsd = {k: v.detach().cpu() for k, v in wt.featurenet.state_dict().items()}
-    csd = {k: v.detach().cpu() for k, v in wt.compress.state_dict().items()}
-    return fsd, csd, costreg_oracle_weights(wt.costreg_sd)
-
-
 @pytest.fixture(scope="module")
 def oracle_volume(full):
     """The ORACLE's own get_conditional_volume from the IMAGES at BASELINE config-2 size (8 x 256^2 views, 128^3): FeatureNet -> fused pyramid ->
     compress layer -> back-projection + aggregation over 2.1 M voxels -> sparse CNN on 1.17 M voxels -> dense scatter (oracle/recon.py,
     ~30 GFLOP on the host: tens of seconds)."""
-    sc, D = full["sc"], full["D"]
-    fsd, csd, cw = _oracle_weight_dicts(full["wt"])
-    with torch.no_grad():
-        return O.conditional_volume(torch.from_numpy(sc["images"]), fsd, csd, cw, torch.from_numpy(sc["affine_mats"]), [D, D, D], 2.0 / (D - 1),
-                                    torch.from_numpy(sc["partial_vol_origin"]))
-
-
-def _rel(a, b):
-    a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    assert a.shape == b.shape, (a.shape, b.shape)
-    return float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+    import fullsize_util as FU
+    return FU.oracle_volume(full["wt"], full["sc"], full["D"])
 
 
 def test_fullsize_volume_vs_oracle(full, oracle_volume):
     """HIP volume build vs the oracle at the BENCHMARKED size (sparse_sdf_network.py:286-400, tsparse/modules.py:259-304): kept-voxel set and
     visible-view counts exact, every intermediate tensor and the dense latent volume within fp32 tolerances."""
-    vol, ov, D = full["vol"], oracle_volume, full["D"]
-    assert torch.equal(vol["coords"].cpu(), ov["coords"])                                         # 1,166,970 kept voxels: exact, same order
-    assert torch.equal(vol["cnt"].cpu().long().view(-1), ov["cnt"].long().view(-1))               # visible-view count of all 128^3 voxels
-    assert torch.equal(vol["maskvol"].view(D, D, D).cpu(), ov["mask"][0, 0])
-    r = {"fused_pyramid": _rel(vol["cmaps"][..., 3:59].permute(0, 3, 1, 2), ov["fmaps"]),
-         "compressed_maps": _rel(vol["feats_nhwc"].permute(0, 3, 1, 2), ov["feats16"]),
-         "cost_volume_rows": _rel(vol["rows"], ov["rows"]), "sparse_cnn_rows": _rel(vol["rows16"], ov["rows16"]),
-         "dense_volume": _rel(vol["vol_cl"].permute(3, 0, 1, 2)[None], ov["dense"])}
+    import fullsize_util as FU
+    r = FU.volume_vs_oracle(full["vol"], oracle_volume, full["D"])
     print("full-size volume build vs oracle (max abs error / max|oracle|):", r)
+    assert r["kept_set_exact"] and r["view_counts_exact"] and r["mask_exact"] and r["kept_voxels"] > 1_000_000, r     # 1,166,970 kept voxels, same order
     assert r["fused_pyramid"] < 5e-5 and r["compressed_maps"] < 5e-5 and r["cost_volume_rows"] < 1e-4, r
     assert r["sparse_cnn_rows"] < 1e-4 and r["dense_volume"] < 1e-4, r
 
@@ -457,49 +436,21 @@ def test_fullsize_mesh_vs_oracle_field(full):
     """north_star: "mesh topology exactly ... at matched mesh IoU".  Marching cubes is exact GIVEN u (tests/test_gpu_parity.py); this test closes
     the loop over the field: on a 64^3 sub-block of the 256^3 extraction lattice that the surface crosses, HIP's u (tabulated-layer-0 lattice
     kernel, f16x3) vs the oracle's extract_fields (sparse_neus_renderer.py:881-905) -- sign disagreements counted and bounded by the field
-    tolerance (a node may only flip where |u| is within 2e-5 of zero), volumetric IoU of the two inside-sets >= 0.999, and the two meshes of the
-    sub-block (HIP marching cubes on HIP's u, the oracle's marching cubes on the oracle's u) compared: cells whose 8-corner sign pattern
-    agrees produce the same triangles, so topology differs only in the cells listed."""
-    from oracle import mc as omc
-    R, B = 256, 64
-    wt, vol = full["wt"], full["vol"]
-    verts, tris, rgb, u = pipeline.extract_mesh(wt, vol, full["proj"], full["cam_pos"], R)
-    ins = (u > 0)
-    # the sub-block (aligned to 32) with the most sign changes along x
-    chg = (ins[1:] != ins[:-1]).float()
-    best, origin = -1, None
-    for x0 in range(0, R - B + 1, 32):
-        for y0 in range(0, R - B + 1, 32):
-            for z0 in range(0, R - B + 1, 32):
-                c = float(chg[x0:x0 + B - 1, y0:y0 + B, z0:z0 + B].sum())
-                if c > best:
-                    best, origin = c, (x0, y0, z0)
-    x0, y0, z0 = origin
-    lin = torch.linspace(-1, 1, R)
-    gx, gy, gz = torch.meshgrid(lin[x0:x0 + B], lin[y0:y0 + B], lin[z0:z0 + B], indexing="ij")
-    pts = torch.stack([gx, gy, gz], -1).reshape(-1, 3)
-    dense = vol["vol_cl"].permute(3, 0, 1, 2).contiguous().cpu()
-    W = {k: torch.from_numpy(np.asarray(v)) for k, v in wt.sdfW.items()}
-    with torch.no_grad():
-        uo = torch.cat([-O.sdf(pts[s:s + (1 << 16)], dense, W)[0][:, 0] for s in range(0, pts.shape[0], 1 << 16)]).view(B, B, B)
-    uh = u[x0:x0 + B, y0:y0 + B, z0:z0 + B].cpu()
-    err = float((uh - uo).abs().max())
-    flips = (uh > 0) != (uo > 0)
-    nflip = int(flips.sum())
-    inter, union = int(((uh > 0) & (uo > 0)).sum()), int(((uh > 0) | (uo > 0)).sum())
-    iou = inter / max(1, union)
-    print(f"sub-block {origin}: {best:.0f} sign changes, max|u_hip - u_oracle| = {err:.2e}, {nflip} flipped nodes of {B ** 3}, IoU {iou:.6f}; "
-          f"flipped nodes (block coords) {torch.nonzero(flips)[:20].tolist()}, |u| there <= {float(uo[flips].abs().max()) if nflip else 0:.2e}")
-    assert best > 1000 and union > 1000
-    assert err < 2e-5 * max(1.0, float(uo.abs().max()))
-    assert nflip == 0 or float(uo[flips].abs().max()) <= err                      # a node flips only where the field is inside the error band
-    assert iou >= 0.999
-    vh, th = ops.marching_cubes(uh.to(dev).contiguous(), 0.0)
-    vo, to = omc.marching_cubes(uo.numpy(), 0.0)
-    if nflip == 0:
-        assert th.shape[0] == to.shape[0] and vh.shape[0] == vo.shape[0]
-        assert np.array_equal(th.cpu().numpy(), to)                               # identical topology, vertex for vertex
-        d = np.abs(vh.cpu().numpy() - vo).max(1)                                  # crossings slide along their lattice edge with the field error
-        assert float(d.max()) < 0.5 and float(d.mean()) < 1e-3, (float(d.max()), float(d.mean()))
+    tolerance (a node may only flip where |u| is inside the error band), volumetric IoU of the two inside-sets >= 0.999, and the two meshes of the
+    sub-block (HIP marching cubes on HIP's u, the oracle's marching cubes on the oracle's u): without a flipped node every cell has the same
+    8-corner sign pattern, hence identical triangles, vertex for vertex."""
+    import fullsize_util as FU
+    R = 256
+    verts, tris, rgb, u = pipeline.extract_mesh(full["wt"], full["vol"], full["proj"], full["cam_pos"], R)
+    r = FU.mesh_field_vs_oracle(ops, full["wt"], full["vol"], u, R, 64)
+    print("mesh field vs oracle:", r)
+    assert r["sign_changes_in_block"] > 1000 and r["inside_nodes_union"] > 1000
+    assert r["field_err_max"] < 2e-5 * max(1.0, r["field_scale"])
+    assert r["mesh_sign_flips"] == 0 or r["abs_u_at_flips_max"] <= r["field_err_max"]            # a node flips only inside the error band
+    assert r["iou"] >= 0.999
+    if r["mesh_sign_flips"] == 0:
+        assert r["hip_mesh"] == r["oracle_mesh"] and r["triangles_identical"]
+        assert r["vertex_shift_max_mean_cells"][0] < 0.5 and r["vertex_shift_max_mean_cells"][1] < 1e-3, r
     else:
-        assert abs(th.shape[0] - to.shape[0]) <= 16 * nflip and abs(vh.shape[0] - vo.shape[0]) <= 12 * nflip
+        n = r["mesh_sign_flips"]
+        assert abs(r["hip_mesh"][1] - r["oracle_mesh"][1]) <= 16 * n and abs(r["hip_mesh"][0] - r["oracle_mesh"][0]) <= 12 * n

@@ -573,3 +573,55 @@ def test_render_trained_regime(dev, ops, variance, air, bg, shift, precision):
     res = RC.three_clause(ops, dev, scene, a, torch.from_numpy(ro), torch.from_numpy(rd), float(sc["query_near_far"][0]),
                           float(sc["query_near_far"][1]), variance, air, bg, precision, label="small_scene")
     assert res["rays_hitting_surface"] > 10, res
+
+
+def test_ray_finalize_stage_initialises_every_slot(dev, ops):
+    """The public stage entry o2345_ray_finalize: the reference's defaults (sdf = 100, gradients = colours = 0, sparse_neus_renderer.py:231) in EVERY
+    slot -- occupied ones included, a caller may evaluate only part of the list --, mid points / section lengths / occupancy vs the oracle, and the
+    list = exactly the occupied slots."""
+    s = small_scene()
+    d = dev_scene(s, dev, ops)
+    ro, rd = rays_for(s, 70, seed=3, center=False)
+    S, R = 24, 70
+    near, far = float(s["sc"]["query_near_far"][0]), float(s["sc"]["query_near_far"][1])
+    z = torch.sort(torch.rand(R, S, generator=torch.Generator().manual_seed(1)) * (far - near) + near, 1).values
+    sd = (far - near) / 64
+    o = ops.ray_finalize(torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev), z.t().contiguous().to(dev), sd, d["maskvol"].reshape(-1), s["D"])
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((R, 1), sd)], 1)
+    mid = z + dists * 0.5
+    pts = torch.from_numpy(ro)[:, None] + torch.from_numpy(rd)[:, None] * mid[..., None]
+    pm = O.mask_nearest(s["mask"][0, 0], pts.reshape(-1, 3)).reshape(R, S)
+    assert torch.equal(o["pm"].t().cpu(), pm) and 0 < int(pm.sum()) < R * S
+    close(o["mid_z"].t(), mid, rel=1e-6, what="mid_z"); close(o["dists"].t(), dists, rel=1e-6, what="dists")
+    close(o["pts"].permute(1, 0, 2), pts, rel=1e-6, what="mid points")
+    assert bool((o["sdf"] == 100).all()) and float(o["grad"].abs().sum()) == 0 and float(o["rgb"].abs().sum()) == 0
+    n = int(o["count"])
+    assert n == int(pm.sum())
+    slots = torch.sort(o["list"][:n].cpu().long()).values
+    assert torch.equal(slots, torch.nonzero(pm.t().reshape(-1) > 0)[:, 0])
+
+
+def test_convolution_precision_is_per_object(dev, ops, monkeypatch):
+    """The numerical mode of FeatureNet / the compress layer belongs to the object (SceneWeights(color_precision=...), featurenet.set_precision), not
+    only to the global O2345_PRECISION: an fp32 object under the default global mode is bit-equal to the same network under a global fp32 mode."""
+    fn = importlib.import_module("one-2-3-45_amd.featurenet")
+    config = importlib.import_module("one-2-3-45_amd.config")
+    pipeline = importlib.import_module("one-2-3-45_amd.pipeline")
+    torch.manual_seed(0)
+    net = fn.FeatureNet().to(dev)
+    comp = fn.ConvBnReLU(56, 16).to(dev)
+    imgs = torch.rand(2, 3, 48, 64, device=dev)
+    with torch.no_grad():
+        monkeypatch.setattr(config, "PRECISION", "f16x3")
+        fn.set_precision(net, "fp32"); fn.set_precision(comp, "fp32")
+        a = [t.clone() for t in net(imgs)] + [comp(fn.fused_pyramid(net, imgs)).clone()]
+        fn.set_precision(net, None); fn.set_precision(comp, None)
+        c = [t.clone() for t in net(imgs)] + [comp(fn.fused_pyramid(net, imgs)).clone()]            # global default: split-f16 matrix cores
+        monkeypatch.setattr(config, "PRECISION", "fp32")
+        b = [t.clone() for t in net(imgs)] + [comp(fn.fused_pyramid(net, imgs)).clone()]
+    for x, y, w in zip(a, b, c):
+        assert torch.equal(x, y)
+        assert not torch.equal(x, w) and float((x - w).abs().max()) < 5e-5 * max(1.0, float(x.abs().max()))
+    monkeypatch.setattr(config, "PRECISION", "f16x3")
+    wt = pipeline.SceneWeights(dev, seed=0, color_precision="fp32")
+    assert wt.featurenet.precision == "fp32" and wt.compress.precision == "fp32" and all(m.precision == "fp32" for m in wt.featurenet.modules() if isinstance(m, fn.ConvBnReLU))

@@ -70,3 +70,34 @@ def test_bench_bare_invocation_spawns_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"],
                         capture_output=True, text=True, timeout=120, env=env2, cwd=root)
     assert r2.returncode != 0 and "--gpus 2" in (r2.stderr + r2.stdout)
+
+
+def _bcast_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sh = importlib.import_module("one-2-3-45_amd.sharding")
+    sh.init("gloo")
+    state = None
+    if rank == 0:                                       # only rank 0 "can reach the checkpoint"
+        g = torch.Generator().manual_seed(5)
+        state = {"sdf_network_lod0": {"sdf_layer.lin0.weight_v": torch.randn(128, 39, generator=g), "sdf_layer.lin0.bias": torch.randn(128, generator=g)},
+                 "variance_network_lod0": {"variance": torch.tensor(0.37)}, "rendering_network_lod0": {"s": torch.tensor(0.2), "base_fc.0.weight": torch.randn(64, 193, generator=g)}}
+    got = sh.broadcast_state_dicts(state)
+    objs = sh.gather_objects({"rank": rank, "ms": 10.0 + rank})
+    q.put((rank, {n: {k: (tuple(v.shape), str(v.dtype), float(v.double().sum())) for k, v in sd.items()} for n, sd in got.items()}, objs))
+    sh.shutdown()
+
+
+def test_two_rank_weight_broadcast_and_per_rank_gather():
+    """The optional shared-backbone broadcast (one flat buffer, one collective) and the per-rank report of bench.py's N > 1 line, on gloo."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    assert res[0][1] == res[1][1]                                          # bit-identical weights on both ranks (same shapes, dtypes, sums)
+    assert res[0][1]["variance_network_lod0"]["variance"][0] == () and abs(res[0][1]["variance_network_lod0"]["variance"][2] - 0.37) < 1e-7
+    assert res[0][1]["rendering_network_lod0"]["base_fc.0.weight"][0] == (64, 193)
+    assert res[0][2] == res[1][2] == [{"rank": 0, "ms": 10.0}, {"rank": 1, "ms": 11.0}]

@@ -54,6 +54,23 @@ def trace(d, out, title):
             o.write(f"| `{n}` | {len(g)} | {sum(g) / 1e3:.3f} | {sum(g) / len(g):.1f} | {g[0]:.1f} | {g[-1]:.1f} | {100 * sum(g) / total:.2f} |\n")
 
 
+def provenance():
+    """What the numbers were measured on: the kernel sources' hash (one-2-3-45_amd/build.py:sources_sha -- bench.py refuses to print counter
+    numbers whose hash differs from the tree it runs in), bench.py's hash (what the driver records as bench_py_sha16) and, when .git travels, HEAD."""
+    import hashlib
+    import importlib
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    meta = {"kernel_sources_sha": importlib.import_module("one-2-3-45_amd.build").sources_sha(),
+            "bench_py_sha16": hashlib.sha256(open(os.path.join(root, "bench.py"), "rb").read()).hexdigest()[:16]}
+    try:
+        meta["git_head"] = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        meta["git_head"] = None                   # the gpurun snapshot carries no .git
+    return meta
+
+
 def pmc(d, out):
     res = collections.defaultdict(dict)
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
@@ -69,6 +86,7 @@ def pmc(d, out):
                 big = [v[1] for v in vals if v[1] >= 0.8 * top]
                 res[k][c] = sum(big) / len(big)
                 res[k]["launches_averaged"] = len(big)
+    res["_meta"] = provenance()
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 
 
