@@ -53,7 +53,9 @@ GRAD_MFMA_FLOP_PER_POINT = {"fp32": 896 * 4096 / 32, "f16x3": 348 * 32768 / 32, 
 SDF_FLOP_SDF_ONLY = 2 * (39 * 128 + 144 * 128 + 144)            # 47,136 per point (SDF-only forward)
 SDF_FLOP_GRAD = 2 * SDF_FLOP_SDF_ONLY                          # + ~47,136 for the input gradient (transposed GEMMs)
 COLOR_FLOP_PER_PAIR = 38544                                    # per (point, view)
-COLOR_KERNEL_PREFIX = "k_color_mfma"                            # the colour kernel the default configuration launches (profiles/*_pmc_*.json key prefix)
+COLOR_KERNEL_PREFIX = "k_color_pts"                             # the colour kernel the default configuration launches (profiles/*_pmc_*.json key prefix)
+# matrix instructions of k_color_pts per evaluated (32-point tile, view) pair in the pooling pass / the network pass, and per tile (shared rows)
+COLOR_PTS_MFMA = {"f16x3": (9, 75, 54, 32 * 32 * 16 * 2), "fp32": (18, 189, 144, 32 * 32 * 2 * 2)}
 
 
 class Timer:
@@ -156,8 +158,11 @@ def kernel_times(wt, vol, inp, outs, D, reps=5, sdf_precision=None, color_precis
         blob, mode = wt.color_xblob, "x3"
     else:
         blob, mode = wt.color_mblob, True
-    res["color_ms"] = timed(lambda: ops.color_points(blob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], inp["proj"], inp["cam_pos"], pts,
-                                                     query_cam=inp["qcam"], index=idx, want_nviews=False, mfma=mode))
+    color = lambda: ops.color_points(blob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], inp["proj"], inp["cam_pos"], pts,
+                                     query_cam=inp["qcam"], index=idx, want_nviews=False, mfma=mode)
+    res["color_ms"] = timed(color)
+    # how much of the (tile, view) grid the kernel evaluated (views that see none of a tile's 32 points are skipped): device-side counters
+    ops.color_stats(True); color(); res["color_work"] = ops.color_stats_read(); ops.color_stats(False)
     return res
 
 
@@ -173,11 +178,18 @@ def network_rooflines(kt, V, sdf_p, col_p):
              "flop_per_unit": flop_alg, "ms": ms, "mfma_pipe_util": units * flop_pipe / (ms * 1e-3) / 1e12 / peak}
         d.update(extra or {})
         return d
-    cname = {"fp32": "k_color_mfma<8,false> (fp32 MFMA)", "f16x3": "k_color_mfma<8,true> (split-f16 MFMA, fp32 accumulate)"}[col_p]
+    cname = {"fp32": "k_color_pts<false,false> (points as columns, fp32 MFMA)", "f16x3": "k_color_pts<true,false> (points as columns, split-f16 MFMA, fp32 accumulate)"}[col_p]
+    cw = kt["color_work"]
+    na, nb_, nt, fl = COLOR_PTS_MFMA[col_p]
+    color_pipe_flop = (na * cw["pairs_pooling"] + nb_ * cw["pairs_network"] + nt * cw["tiles"]) * fl        # what the matrix pipe executed in that launch
     sname = {"fp32": ("k_sdf_mlp<0>", "k_sdf_mlp<2>"), "f16x3": ("k_sdf_mlp_x3", "k_sdf_grad_x3"), "bf16": ("k_sdf_mlp_bf16<0>", "k_sdf_mlp_bf16<2>")}[sdf_p]
     return {
-        "color": blk(cname + ": Projector + GeneralRenderingNetwork", nvp * V, COLOR_FLOP_PER_PAIR, COLOR_MFMA_FLOP_PER_PAIR[col_p],
-                     kt["color_ms"], MFMA_PEAK[col_p]),
+        "color": blk(cname + ": Projector + GeneralRenderingNetwork", nvp * V, COLOR_FLOP_PER_PAIR, color_pipe_flop / max(1, nvp * V),
+                     kt["color_ms"], MFMA_PEAK[col_p],
+                     {"tile_view_pairs": cw["tiles"] * V, "pairs_evaluated_pooling_pass": cw["pairs_pooling"], "pairs_evaluated_network_pass": cw["pairs_network"],
+                      "tiles_evaluating_every_view": cw["tiles_all_views"],
+                      "note": "units = occupied points x views = the reference's work (it evaluates every pair); the kernel skips, bit-identically, the views "
+                              "that see none of a tile's 32 points -- `achieved` counts the reference's FLOP, `mfma_pipe_util` the instructions actually executed"}),
         "sdf": blk(sname[0] + ": SDF forward on all sample points", npts, SDF_FLOP_SDF_ONLY, SDF_MFMA_FLOP_PER_POINT[sdf_p], kt["sdf_mlp_ms"],
                    MFMA_PEAK[sdf_p]),
         "sdf_grad": blk(sname[1] + ": SDF + analytic gradient, occupied points", nvp, SDF_FLOP_GRAD, GRAD_MFMA_FLOP_PER_POINT[sdf_p],

@@ -232,6 +232,11 @@ int o2345_color_points_mfma(const float* blob, const float* vol_cl, const float*
                             const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
                             const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
                             const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
+/* diagnostics of the points-as-columns colour kernel (no reference counterpart): enable != 0 zeroes four device counters that every following launch
+ * of this process adds to -- [0] (32-point tile, view) pairs evaluated in the pooling pass, [1] in the network pass, [2] tiles, [3] tiles that evaluated
+ * every view because one of their points has no visible view; read copies them to the host (synchronises the stream) */
+int o2345_color_stats_enable(int enable, void* stream);
+int o2345_color_stats_read(unsigned long long* out4, void* stream);
 /* same kernel, split-f16 matrix steps (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulate; fp32-class
  * accuracy, see o2345_sdf_mlp_x3); blob from weights.pack_color_x3_blob */
 int o2345_color_x3_blob_floats(void);

@@ -305,15 +305,12 @@ static int color_mfma_launch(bool x3, const float* blob, const float* vol_cl, co
     O2345_REQUIRE(V >= 1 && V <= 255, "color_points_mfma: V must be in [1,255] (valid-view counts are stored as uint8; got %d)", V);
     if (n <= 0 && !n_dev) return 0;
     {
-        // Two kernels compute the same function: k_color_mfma (columns = (point, view) pairs, view count padded to a
-        // power of two <= 32) and k_color_pts (columns = points, any V).  On MI355X they are equally fast at V = 8 (45.5 vs 45.2 ms on 29.5 M
-        // points) and k_color_mfma wins at V = 32 (50 vs 55 ms); k_color_pts wins whenever the padding wastes lanes (V = 5..7, 9..15, 17..31)
-        // and is the only matrix-core form for V > 32.  O2345_COLOR_KERNEL=tiles|pts overrides the choice (A/B runs).
-        int G = 4;
-        while (G < V) G <<= 1;
-        bool use_pts = V > 32 || G != V;
+        // Two kernels compute the same function: k_color_pts (columns = points, any view count; views that see none of a
+        // tile's points are skipped) and k_color_mfma (columns = (point, view) pairs, view count padded to a power of two <= 32: every pair is
+        // evaluated).  Measured on MI355X (tools/ab_sched.py, split-f16 form): 8 views / 29.5 M points 41.7 vs 47.7 ms, 32 views / 8.3 M points
+        // 46.3 vs 52.3 ms -> k_color_pts is the default for every view count; O2345_COLOR_KERNEL=tiles selects k_color_mfma (A/B runs, tests).
+        bool use_pts = true;
         const char* e = getenv("O2345_COLOR_KERNEL");
-        if (e && e[0] == 'p') use_pts = true;
         if (e && e[0] == 't' && V <= 32) use_pts = false;
         if (use_pts)
             return color_pts_launch(x3 ? 1 : 0, blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals,

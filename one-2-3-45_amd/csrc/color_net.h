@@ -63,13 +63,19 @@ struct ColorMArgs {
     const float* f_rgb;       // [V,P,59]  colours (3) | features (56)
     const float* f_rdiff;     // [V,P,4]
     const float* f_mask;      // [V,P]     non-zero = the projection is valid
-    int sched;                // wave-scheduling knobs (O2345_COLOR_SCHED, A/B runs): bit 0 = static priority by SIMD slot (the k-th wave of a SIMD
-                              // runs at priority k), bit 1 = priority 3 while a wave issues its pixel gathers
+    unsigned long long* stats;  // optional device counters (o2345_color_stats_enable): [0] += (tile, view) pairs evaluated in pass A, [1] += in pass B,
+                              // [2] += tiles, [3] += tiles that evaluated every view in pass B because one of their points has no visible view
+    int sched;                // scheduling knobs (O2345_COLOR_SCHED; default 10 = bits 1 + 3, measured on MI355X with tools/ab_sched.py):
+                              //   bit 0  static wave priority by SIMD slot (the k-th wave of a SIMD runs at priority k): no gain
+                              //   bit 1  priority 3 while a wave issues its pixel gathers: -1.5 %
+                              //   bit 2  k_color_pts evaluates EVERY view (no skipping of views that see none of a tile's points): +13 % (the round-2 kernel)
+                              //   bit 3  k_color_pts: block-interleaved tile schedule instead of one contiguous eighth of the list per XCD -- with view
+                              //          skipping a tile's cost depends on where its rays look: -1 % at 8 views, -20 % at 32 views
 };
 
 inline int color_sched_mode() {
     const char* e = getenv("O2345_COLOR_SCHED");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : 10;
 }
 #if defined(__HIPCC__)
 __device__ __forceinline__ void set_wave_prio(int p) {       // s_setprio takes an immediate

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
     // cost of a tile depends on where its rays look, and a contiguous eighth of the image is not an eighth of the work)
     const TileSched ts = (a.sched & 8) ? TileSched{(long long)blockIdx.x * nwave + wave, (n + 31) / 32, (long long)gridDim.x * nwave}
                                        : tile_schedule(n, 32, wave, nwave);
+    unsigned st_a = 0, st_b = 0, st_t = 0, st_full = 0;          // wave-uniform work counters (a.stats)
     for (long long tile = ts.first; tile < ts.end; tile += ts.stride) {
         const long long i = tile * 32 + j;
         const bool live = i < n;
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
                 // coherent: at BASELINE config 2 a point is seen by 4.8 of the 8 views on average and 37 % of the (tile, view) pairs are skipped.
                 if (skip_views && __builtin_amdgcn_ballot_w64(g.m != 0.f) == 0ull) continue;
                 active |= 1ull << (v & 63);
+                ++st_a;
                 float rf[32];
                 if constexpr (FEATS) load_feats(a, h, v, slot, rf);
                 else {
@@ -259,9 +261,12 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
         // visible view, whatever the order.  Only a point with NO visible view blends the masked views (uniformly): if the tile holds such a
         // point, every view is evaluated as before; otherwise the views that see none of the tile's points are skipped -- bit-identical results.
         const bool skip_b = skip_views && __builtin_amdgcn_ballot_w64(live && nvis == 0.f) == 0ull;
+        ++st_t;
+        st_full += skip_b ? 0u : 1u;
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
             if (skip_b && !((active >> (v & 63)) & 1ull)) continue;
+            ++st_b;
             const ViewGeom g = FEATS ? feat_geom(a, v, slot, s_abs) : view_geom(a, v, px, py, pz, qx, qy, qz, gvalid, s_abs);
             const float m = g.m;
             float rf[32];
@@ -369,11 +374,19 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
             if (a.out_nviews) a.out_nviews[slot] = (uint8_t)(nvis + 0.5f);
         }
     }
+    if (a.stats && lane == 0) {
+        atomicAdd(a.stats + 0, (unsigned long long)st_a); atomicAdd(a.stats + 1, (unsigned long long)st_b);
+        atomicAdd(a.stats + 2, (unsigned long long)st_t); atomicAdd(a.stats + 3, (unsigned long long)st_full);
+    }
 }
 
 }  // namespace o2345
 
 namespace o2345 {
+
+// work counters of the colour kernel (diagnostics for bench.py's matrix-pipe utilisation: how many (tile, view) pairs were evaluated)
+static unsigned long long* g_color_stats = nullptr;
+unsigned long long* color_stats_buffer() { return g_color_stats; }
 
 // launcher shared by o2345_color_points_mfma / o2345_color_points_x3 (csrc/color_mfma.hip decides which kernel runs)
 int color_pts_launch(int x3, const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps, const float* proj,
@@ -381,6 +394,7 @@ int color_pts_launch(int x3, const float* blob, const float* vol_cl, const float
                            long long n, const float* query_cam, const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream) {
     ColorMArgs a{blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews};
     a.sched = color_sched_mode();
+    a.stats = g_color_stats;
     const int n_cu = cu_count();
     const int threads = CP_THREADS;
     const long long per_block = (long long)(threads / 64) * 32;
@@ -479,3 +493,27 @@ int color_feats_launch(int x3, const float* blob, const float* geo, const float*
 }
 
 }  // namespace o2345
+
+extern "C" {
+
+// Diagnostics: enable != 0 allocates (once) and zeroes four device counters that every following k_color_pts launch of this process adds to;
+// enable == 0 stops counting.  o2345_color_stats_read copies them to the host (synchronises the stream):
+// out[0] = (32-point tile, view) pairs evaluated in pass A, out[1] = in pass B, out[2] = tiles, out[3] = tiles that evaluated every view in pass B.
+int o2345_color_stats_enable(int enable, void* stream) {
+    using namespace o2345;
+    if (!enable) { g_color_stats = nullptr; return 0; }
+    static unsigned long long* buf = nullptr;
+    if (!buf) O2345_HIP(hipMalloc(&buf, 4 * sizeof(unsigned long long)));
+    O2345_HIP(hipMemsetAsync(buf, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));
+    g_color_stats = buf;
+    return 0;
+}
+int o2345_color_stats_read(unsigned long long* out4, void* stream) {
+    using namespace o2345;
+    O2345_REQUIRE(out4 && g_color_stats, "color_stats_read: counters are not enabled");
+    O2345_HIP(hipMemcpyAsync(out4, g_color_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    O2345_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -438,6 +438,18 @@ def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=Non
     return rgb, nv
 
 
+def color_stats(enable=True):
+    """Diagnostics: zero and enable (or disable) the work counters of the points-as-columns colour kernel for the following launches of this process."""
+    check(_lib.lib().o2345_color_stats_enable(int(bool(enable)), _stream()), "color_stats_enable")
+
+
+def color_stats_read():
+    """-> dict(pairs_pooling, pairs_network, tiles, tiles_all_views): (32-point tile, view) pairs evaluated by the two passes since color_stats()."""
+    out = (ctypes.c_ulonglong * 4)()
+    check(_lib.lib().o2345_color_stats_read(out, _stream()), "color_stats_read")
+    return dict(pairs_pooling=int(out[0]), pairs_network=int(out[1]), tiles=int(out[2]), tiles_all_views=int(out[3]))
+
+
 @_on_device
 def project_features(vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=None, normals=None):
     """Projector.compute (query_cam) / compute_view_independent (normals) materialised in the reference's layout:

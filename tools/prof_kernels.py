@@ -22,7 +22,7 @@ for _ in range(2):        # the kernels of the default (f16x3) mode, full-size l
     ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=2, index=idx, out=o2, precision="f16x3")
     ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=0, out={"sdf": o2["sdf"]}, precision="f16x3")
     ops.color_points(wt.color_xblob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], inp["proj"], inp["cam_pos"], pts, query_cam=inp["qcam"], index=idx, want_nviews=False, mfma="x3")
-    os.environ["O2345_COLOR_KERNEL"] = "pts"          # the second colour kernel on the same points (A/B evidence)
+    os.environ["O2345_COLOR_KERNEL"] = "tiles"        # the other colour kernel (columns = (point, view) pairs, every pair evaluated) on the same points (A/B evidence)
     ops.color_points(wt.color_xblob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], inp["proj"], inp["cam_pos"], pts, query_cam=inp["qcam"], index=idx, want_nviews=False, mfma="x3")
     os.environ.pop("O2345_COLOR_KERNEL")
     ops.costvol_gather(vol["feats_nhwc"], inp["aff"], (D, D, D), 2.0 / (D - 1), inp["origin"], vol["cnt"], vol["coords"])
