@@ -57,5 +57,22 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(tag, defines):
+    """A second library for A/B runs on ONE box (tools/ab_lib.py): every source recompiled with extra -D flags into build_<tag>/,
+    linked as libo2345_hip_<tag>.so next to the product library (git-ignored; travels with the gpurun snapshot)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build_" + tag)
+    os.makedirs(objdir, exist_ok=True)
+    lib = os.path.join(HERE, f"libo2345_hip_{tag}.so")
+
+    def run(src):
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + list(defines) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", os.path.join(objdir, src + ".o")]
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, SOURCES))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [os.path.join(objdir, s + ".o") for s in SOURCES])
+    return lib
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

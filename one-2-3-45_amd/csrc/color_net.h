@@ -149,6 +149,8 @@ __device__ __forceinline__ Split8 split8(const float (&b)[N], int s0, float m1) 
         const float x = (s0 + 2 * i < N) ? b[s0 + 2 * i < N ? s0 + 2 * i : 0] : 0.f;
         const float y = (s0 + 2 * i + 1 < N) ? b[s0 + 2 * i + 1 < N ? s0 + 2 * i + 1 : 0] : 0.f;
         hi.v2[i] = __builtin_amdgcn_cvt_pkrtz(x, y);
+        // (the v_fma_mixlo_f16 / v_fma_mixhi_f16 form of csrc/sdf_mlp_x3.hip was measured here too: 40.9 vs 39.6 ms for k_color_pts -- the two-instruction
+        // asm block constrains the scheduler more than it saves -- so the colour kernels keep the three-instruction C form)
         lo.v2[i] = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)hi.w2[i][0], m1, x), __builtin_fmaf((float)hi.w2[i][1], m1, y));
     }
     return {hi.v8, lo.v8};
@@ -167,6 +169,29 @@ __device__ __forceinline__ void cx_run(f32x16 (&acc)[NB], const float4* A /* seg
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA_F16(alo[nb], sp.hi, acc[nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA_F16(ahi[nb], sp.lo, acc[nb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA_F16(ahi[nb], sp.hi, acc[nb]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// the same with the accumulators STARTING from `init` (the first matrix instruction of every block reads it as its C operand and writes `acc`: no
+// register copies of a value that must stay live, e.g. the view-independent rows shared by all views of a point)
+template <int NB, int N>
+__device__ __forceinline__ void cx_run_from(f32x16 (&acc)[NB], const f32x16 (&init)[NB], const float4* A, const float (&b)[N], float m1) {
+    constexpr int NS = (N + 7) / 8;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const Split8 sp = split8(b, 8 * s, m1);
+        h16x8 ahi[NB], alo[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            ahi[nb] = __builtin_bit_cast(h16x8, A[((nb * NS + s) * 2 + 0) * 64]);
+            alo[nb] = __builtin_bit_cast(h16x8, A[((nb * NS + s) * 2 + 1) * 64]);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA_F16(alo[nb], sp.hi, s == 0 ? init[nb] : acc[nb]);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA_F16(ahi[nb], sp.lo, acc[nb]);
 #pragma unroll

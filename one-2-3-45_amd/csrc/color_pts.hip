@@ -286,8 +286,9 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
             // ---- base_fc: (shared + 59 per-view features) -> 64 -> 32
             f32x16 x32[1];
             {
-                f32x16 acc[2] = {sh[0], sh[1]};
-                cm_layer<X3, 2, 32>(acc, lds, lane, CM_A_B0, CX_A_B0, rf, m1);
+                f32x16 acc[2];
+                if constexpr (X3) cx_run_from<2, 32>(acc, sh, reinterpret_cast<const float4*>(lds + CX_A_B0) + lane, rf, m1);
+                else { acc[0] = sh[0]; acc[1] = sh[1]; cm_layer<X3, 2, 32>(acc, lds, lane, CM_A_B0, CX_A_B0, rf, m1); }
                 float hb[32];
 #pragma unroll
                 for (int b = 0; b < 2; ++b)

@@ -95,6 +95,23 @@ inline unsigned persistent_grid(long long want, int n_cu) {
 }
 
 #if defined(__HIPCC__)
+// Residual halves of the split-f16 operand form: lo = f16(x - hi) for a PAIR of values whose hi halves are packed in `hi` -- v_fma_mixlo_f16 /
+// v_fma_mixhi_f16 take the f16 half as an operand, subtract exactly in fp32 and write the rounded f16 straight into the low / high half of the
+// result: 2 instructions per pair instead of 2 x v_fma_mix_f32 + v_cvt_pkrtz (hipcc does not select them from C code; checked value by value against
+// the C form on hardware, tools/ubench/mixlo_check.hip: identical up to the rounding of the residual, nearest instead of toward zero).  Used by the SDF
+// kernels (csrc/sdf_mlp_x3.hip): k_sdf_grad_x3 drops from 2766 to 2650 vector instructions and, more importantly, below the 256-register line -- its
+// 224 bytes per lane of scratch disappear: 11.9 -> 9.9 ms on 29.5 M points.  O2345_SPLIT_MIXLO=0 builds the three-instruction form (A/B).
+#ifndef O2345_SPLIT_MIXLO
+#define O2345_SPLIT_MIXLO 1
+#endif
+__device__ __forceinline__ unsigned split_lo_pair_bits(unsigned hi_bits, float a, float b) {
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo) : "v"(hi_bits), "v"(a), "v"(b));
+    return lo;
+}
+
 // Tile schedule of the persistent network kernels.  Workgroups are dispatched round-robin over the 8 XCDs (block b runs on XCD
 // b % 8) and every XCD has its own 4 MB L2: handing consecutive tiles to consecutive blocks makes each XCD stream the whole
 // working set (source-view maps, latent volume) through its L2.  Instead every XCD gets one contiguous eighth of the tile list

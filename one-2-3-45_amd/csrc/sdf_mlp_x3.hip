@@ -29,12 +29,16 @@ __device__ __forceinline__ float opaque_minus_one() {
     return m1;
 }
 __device__ __forceinline__ Split8 split8(const float* v, float m1) {
-    union { h16x8 v8; h16x2 v2[4]; hh16x2 w2[4]; } hi, lo;
+    union { h16x8 v8; h16x2 v2[4]; hh16x2 w2[4]; unsigned u[4]; } hi, lo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float a = v[2 * i], b = v[2 * i + 1];
         hi.v2[i] = __builtin_amdgcn_cvt_pkrtz(a, b);
+#if O2345_SPLIT_MIXLO
+        lo.u[i] = split_lo_pair_bits(hi.u[i], a, b);
+#else
         lo.v2[i] = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)hi.w2[i][0], m1, a), __builtin_fmaf((float)hi.w2[i][1], m1, b));
+#endif
     }
     return {hi.v8, lo.v8};
 }
