@@ -150,8 +150,12 @@ __device__ __forceinline__ Split8 split8(const float (&b)[N], int s0, float m1) 
         const float y = (s0 + 2 * i + 1 < N) ? b[s0 + 2 * i + 1 < N ? s0 + 2 * i + 1 : 0] : 0.f;
         hi.v2[i] = __builtin_amdgcn_cvt_pkrtz(x, y);
         // (the v_fma_mixlo_f16 / v_fma_mixhi_f16 form of csrc/sdf_mlp_x3.hip was measured here too: 40.9 vs 39.6 ms for k_color_pts -- the two-instruction
-        // asm block constrains the scheduler more than it saves -- so the colour kernels keep the three-instruction C form)
+        // asm block constrains the scheduler more than it saves -- so the colour kernels keep the three-instruction C form; -DO2345_COLOR_SPLIT_MIXLO=1: A/B)
+#if defined(O2345_COLOR_SPLIT_MIXLO) && O2345_COLOR_SPLIT_MIXLO
+        lo.v2[i] = __builtin_bit_cast(h16x2, split_lo_pair_bits(__builtin_bit_cast(unsigned, hi.v2[i]), x, y));
+#else
         lo.v2[i] = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)hi.w2[i][0], m1, x), __builtin_fmaf((float)hi.w2[i][1], m1, y));
+#endif
     }
     return {hi.v8, lo.v8};
 }

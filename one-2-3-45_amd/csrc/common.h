@@ -106,9 +106,11 @@ inline unsigned persistent_grid(long long want, int n_cu) {
 #endif
 __device__ __forceinline__ unsigned split_lo_pair_bits(unsigned hi_bits, float a, float b) {
     unsigned lo;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : "=&v"(lo) : "v"(hi_bits), "v"(a), "v"(b));
+    // `volatile` matters: as a "pure" asm the pair gave wrong colours in k_color_mfma (G < 32) on hardware while s_nop-padded and volatile builds of the same
+    // source were correct -- LLVM moves / merges side-effect-free asm in ways the EXEC-ignoring matrix instructions that consume the result do not survive
+    asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+                 "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                 : "=&v"(lo) : "v"(hi_bits), "v"(a), "v"(b));
     return lo;
 }
 
