@@ -22,30 +22,6 @@
 
 namespace o2345 {
 
-// geometry of one source view for this lane's point: ray_diff (4), pooling exponent, projection mask and the bilinear taps
-struct ViewGeom {
-    float rd[4];
-    float e;          // 2^(s_abs * (dot - 1))
-    float m;          // 1 if the point is valid and projects inside view v
-    float gx, gy;
-};
-
-__device__ __forceinline__ ViewGeom view_geom(const ColorMArgs& a, int v, float px, float py, float pz, float qx, float qy, float qz,
-                                              bool gvalid, float s_abs) {
-    ViewGeom g;
-    cm_project(a.proj + 12 * v, px, py, pz, a.H, a.W_img, g.gx, g.gy);
-    g.m = (gvalid && fabsf(g.gx) < 1.f && fabsf(g.gy) < 1.f) ? 1.f : 0.f;
-    const float sx = a.cam_pos[3 * v] - px, sy = a.cam_pos[3 * v + 1] - py, sz = a.cam_pos[3 * v + 2] - pz;
-    const float rsn = crcp(sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f);
-    const float ux = sx * rsn, uy = sy * rsn, uz = sz * rsn;
-    const float dx = qx - ux, dy = qy - uy, dz = qz - uz;
-    const float rdn = crcp(fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f));
-    g.rd[0] = dx * rdn; g.rd[1] = dy * rdn; g.rd[2] = dz * rdn;
-    g.rd[3] = qx * ux + qy * uy + qz * uz;
-    g.e = __builtin_amdgcn_exp2f(s_abs * (g.rd[3] - 1.f));       // s_abs carries log2(e)
-    return g;
-}
-
 // this half's 32 pixel floats of view v at (g.gx, g.gy), bilinear, ATen zero padding, in the log2(e)-scaled domain.
 // (Measured alternatives, all slower on MI355X: branch-free taps 50-59 ms; taps of view v + 1 requested during the network of view v
 // -- one tap, 32 registers, at a time -- 48.4 ms; lane octets fetching whole 128-byte half pixels through global_load_lds into a per-wave
