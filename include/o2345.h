@@ -232,13 +232,6 @@ int o2345_color_points_mfma(const float* blob, const float* vol_cl, const float*
                             const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
                             const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
                             const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
-/* 16-column form of the same function for up to 8 source views (csrc/color_c16.hip: v_mfma_f32_16x16x32_f16, a point's per-view network inputs stay in
- * registers between the pooling pass and the network pass -- no second gather); split-f16 numerical form; blob from weights.pack_color_c16_blob */
-int o2345_color_c16_blob_floats(void);
-int o2345_color_points_c16(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
-                           const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
-                           const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
-                           const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
 /* diagnostics of the points-as-columns colour kernel (no reference counterpart): enable != 0 zeroes four device counters that every following launch
  * of this process adds to -- [0] (32-point tile, view) pairs evaluated in the pooling pass, [1] in the network pass, [2] tiles, [3] tiles that evaluated
  * every view because one of their points has no visible view; read copies them to the host (synchronises the stream) */

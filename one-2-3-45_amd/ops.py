@@ -422,7 +422,7 @@ def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=Non
                  want_nviews=True, mfma=False):
     """mfma=False: VALU kernel (blob from weights.pack_color_blob, V <= 64); mfma=True: fp32 matrix-core kernels (pack_color_mfma_blob);
     mfma="x3": the same kernels with split-f16 matrix steps (pack_color_x3_blob).  The matrix-core path takes any view count up to 255
-    (k_color_pts by default, k_color_mfma with O2345_COLOR_KERNEL=tiles); mfma="c16": the 16-column split-f16 kernel for V <= 8 (pack_color_c16_blob)."""
+    (k_color_pts by default, k_color_mfma with O2345_COLOR_KERNEL=tiles)."""
     V, H, W, _ = cmaps.shape
     P = pts.shape[0]
     n = P if index is None else index.shape[0]
@@ -431,7 +431,7 @@ def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=Non
     if P == 0 or (n == 0 and n_dev is None):
         return rgb, nv
     L = _lib.lib()
-    fn = {"x3": L.o2345_color_points_x3, "c16": L.o2345_color_points_c16}.get(mfma) or (L.o2345_color_points_mfma if mfma else L.o2345_color_points)
+    fn = L.o2345_color_points_x3 if mfma == "x3" else (L.o2345_color_points_mfma if mfma else L.o2345_color_points)
     check(fn(_p(blob), _p(vol_cl), _p(maskvol), vol_cl.shape[0], _p(cmaps), _p(proj), _p(cam_pos),
                                         V, H, W, _p(pts), _p(index, torch.int32), _p(n_dev, torch.int32), n, _p(query_cam),
                                         _p(normals), _p(rgb), _p(nv, torch.uint8), _stream()), "color_points")

@@ -508,125 +508,3 @@ def pack_color_x3_blob(sd):
     sec[:, :, 0], sec[:, :, 1] = hi, lo
     return blob
 
-
-# ---- colour network, 16-column form (csrc/color_c16.hip): v_mfma_f32_16x16x32_f16, split-f16 --------------------------------------
-# A wave owns 16 POINTS (column n = lane & 15); the four lane groups g = lane >> 4 supply 8 of the 32 k values of a step each and
-# receive output rows 4g .. 4g+3 of every 16-row block.  A lane owns pixel floats 16g .. 16g+15 of its point.  Because a lane then
-# holds only 16 floats per (point, view), the inputs of the per-view network for up to 8 views fit in registers (128 of them), and
-# the second pass neither gathers nor evaluates ray_dir_fc again.
-# A segments: [block][k-step of 32][hi|lo][64 lanes][8 f16]; bias vectors [block][group][4] fp32.
-C16_SEGS = [("RD0", 1, 1), ("RD1", 4, 1), ("B0", 4, 2), ("B1", 2, 2), ("V0", 2, 1), ("V1", 3, 1), ("V20", 2, 1), ("V21", 1, 1),
-            ("R0", 1, 2), ("R1", 1, 1), ("R2", 1, 1), ("S", 4, 5)]
-
-
-def _c16_layout():
-    off, segs = 0, {}
-    for name, nb, ns in C16_SEGS:
-        segs["A_" + name] = (off, nb, ns)
-        off += nb * ns * 512
-    a_end = off
-    for name, nb, _ in C16_SEGS:
-        if name == "S":
-            continue                               # the shared rows start from base_fc.0's bias (B0)
-        segs["B_" + name] = (off, nb)
-        off += nb * 16
-    segs["SCALAR"] = (off, 4)
-    off += 4
-    return segs, a_end, off
-
-
-C16_LAYOUT, C16_A_END, C16_BLOB_FLOATS = _c16_layout()
-
-
-def c16_slot_neuron(g, j, nblocks_per_step=2, s=0):
-    """k enumeration of a layer whose input is the OUTPUT of a 16-row-block layer: slot j (0..7) of lane group g in k-step s is
-    output row 4g + j % 4 of block 2s + j // 4."""
-    return 16 * (2 * s + j // 4) + 4 * g + j % 4
-
-
-def pack_color_c16_blob(sd):
-    g_ = lambda k: np.asarray(sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k], np.float32)
-    blob = np.zeros(C16_BLOB_FLOATS, np.float32)
-    L, N = np.float32(1.4426950408889634), np.float32(0.6931471805599453)
-
-    def fill(name, W, row_of, col_of):
-        """A[b][s][lane (m, g)][j] = W[row_of(b, m)][col_of(s, g, j)] (zero where an index is None / out of range), split hi | lo."""
-        off, nb, ns = C16_LAYOUT["A_" + name]
-        F = np.zeros((nb, ns, 64, 8), np.float32)
-        for b in range(nb):
-            for s in range(ns):
-                for l in range(64):
-                    m, gg = l & 15, l >> 4
-                    o = row_of(b, m)
-                    if o is None or o >= W.shape[0]:
-                        continue
-                    for j in range(8):
-                        k = col_of(s, gg, j)
-                        if k is not None and k < W.shape[1]:
-                            F[b, s, l, j] = W[o, k]
-        hi, lo = f16_split(F)
-        sec = blob[off:off + nb * ns * 512].view(np.float16).reshape(nb, ns, 2, 64, 8)
-        sec[:, :, 0], sec[:, :, 1] = hi, lo
-
-    def bias(name, bvec, row_of):
-        off, nb = C16_LAYOUT["B_" + name]
-        a = blob[off:off + nb * 16].reshape(nb, 4, 4)               # [block][group][i]: row 4g + i
-        for b in range(nb):
-            for gg in range(4):
-                for i in range(4):
-                    o = row_of(b, 4 * gg + i)
-                    if o is not None and o < bvec.shape[0]:
-                        a[b, gg, i] = bvec[o]
-
-    plain = lambda b, m: 16 * b + m
-    chain1 = lambda s, gg, j: c16_slot_neuron(gg, j, s=s)                                     # input = blocks (2s, 2s+1) of the previous layer
-    one_block = lambda s, gg, j: (4 * gg + j) if j < 4 else None                              # input = ONE 16-row block (4 values per lane)
-    # ray_dir_fc.0: rd[0..3] in slots 0..3 of lane group 0
-    fill("RD0", g_("ray_dir_fc.0.weight") * L, plain, lambda s, gg, j: j if (gg == 0 and j < 4) else None)
-    bias("RD0", g_("ray_dir_fc.0.bias") * L, plain)
-    # ray_dir_fc.2: output row (block b, row m = 4g + i) is the direction feature of pixel float 16g + 4b + i (the lane's own floats)
-    rd1_row = lambda b, m: (16 * (m // 4) + 4 * b + m % 4) if (16 * (m // 4) + 4 * b + m % 4) < 59 else None
-    fill("RD1", g_("ray_dir_fc.2.weight"), rd1_row, one_block)
-    bias("RD1", g_("ray_dir_fc.2.bias") * L, rd1_row)
-    w_b0 = g_("base_fc.0.weight")
-    fill("B0", w_b0, plain, lambda s, gg, j: (134 + 16 * gg + 8 * s + j) if (16 * gg + 8 * s + j) < 59 else None)
-    bias("B0", g_("base_fc.0.bias") * L, plain)
-    fill("B1", g_("base_fc.2.weight"), plain, chain1)
-    bias("B1", g_("base_fc.2.bias") * L, plain)
-    rep = lambda row: (lambda b, m: row)                                                       # every row of the block = one output row
-    fill("V0", g_("vis_fc.0.weight"), plain, chain1)
-    bias("V0", g_("vis_fc.0.bias") * L, plain)
-    v1_row = lambda b, m: (16 * b + m) if b < 2 else 32
-    fill("V1", g_("vis_fc.2.weight"), v1_row, chain1)
-    bias("V1", g_("vis_fc.2.bias") * L, v1_row)
-    fill("V20", g_("vis_fc2.0.weight"), plain, chain1)
-    bias("V20", g_("vis_fc2.0.bias") * L, plain)
-    fill("V21", g_("vis_fc2.2.weight"), rep(0), chain1)
-    bias("V21", g_("vis_fc2.2.bias") * L, rep(0))
-    w_r0 = g_("rgb_fc.0.weight").copy()
-    w_r0[:, 32:] *= L                                                                          # visibility and ray directions are not in the scaled domain
-    fill("R0", w_r0, plain, lambda s, gg, j: chain1(0, gg, j) if s == 0 else ((32 + j) if (gg == 0 and j < 5) else None))
-    bias("R0", g_("rgb_fc.0.bias") * L, plain)
-    fill("R1", g_("rgb_fc.2.weight"), lambda b, m: m if m < 8 else None, one_block)
-    bias("R1", g_("rgb_fc.2.bias") * L, lambda b, m: m if m < 8 else None)
-    fill("R2", g_("rgb_fc.4.weight"), rep(0), lambda s, gg, j: (4 * gg + j) if (gg < 2 and j < 4) else None)
-    bias("R2", g_("rgb_fc.4.bias") * L, rep(0))
-    # view-independent rows of base_fc.0: per lane geo (4) | mean (16) | var (16) of ITS channels; columns of W_b0: geo 0..15, mean 16..74, var 75..133
-    ws = np.zeros((64, 16 + 64 + 64), np.float32)
-    ws[:, :16] = w_b0[:, :16] * L
-    ws[:, 16:16 + 59] = w_b0[:, 16:75]
-    ws[:, 80:80 + 59] = w_b0[:, 75:134] * N
-
-    def shared_col(s, gg, j):
-        t = 8 * s + j
-        if t < 4:
-            return 4 * gg + t
-        if t < 20:
-            return 16 + 16 * gg + (t - 4)
-        if t < 36:
-            return 80 + 16 * gg + (t - 20)
-        return None
-    fill("S", ws, plain, shared_col)
-    so = C16_LAYOUT["SCALAR"][0]
-    blob[so] = g_("s").reshape(-1)[0]
-    return blob

@@ -51,7 +51,6 @@ def dev_scene(s, dev, ops):
                 sdf_blob=t(pkg.weights.pack_sdf_blob(s["sdfW"])), color_blob=t(pkg.weights.pack_color_blob(s["color_sd"])),
                 color_mfma_blob=t(pkg.weights.pack_color_mfma_blob(s["color_sd"])),
                 color_x3_blob=t(pkg.weights.pack_color_x3_blob(s["color_sd"])),
-                color_c16_blob=t(pkg.weights.pack_color_c16_blob(s["color_sd"])),
                 aff=t(sc["affine_mats"]).contiguous())
 
 
@@ -446,7 +445,7 @@ def test_marching_cubes(dev, ops):
                                            ("x3", 4, "tiles"), ("x3", 8, "tiles"), ("x3", 12, "tiles"), ("x3", 32, "tiles"),
                                            (True, 4, "pts"), (True, 5, "pts"), (True, 8, "pts"), (True, 32, "pts"),
                                            ("x3", 4, "pts"), ("x3", 5, "pts"), ("x3", 8, "pts"), ("x3", 12, "pts"), ("x3", 32, "pts"),
-                                           ("x3", 5, None), ("x3", 8, None), ("c16", 4, None), ("c16", 5, None), ("c16", 8, None)])
+                                           ("x3", 5, None), ("x3", 8, None)])
 def test_color_points(dev, ops, mfma, V, kernel, monkeypatch):
     """Both matrix-core kernels in both numerical forms (+ the VALU kernel): "tiles" = k_color_mfma (columns = (point, view) pairs; V = 4 / 8 /
     12 / 32 exercise its G = 4 / 8 / 16 / 32 lane groups incl. padded views for V = 12), "pts" = k_color_pts (columns = points, any V);
@@ -457,7 +456,7 @@ def test_color_points(dev, ops, mfma, V, kernel, monkeypatch):
         monkeypatch.delenv("O2345_COLOR_KERNEL", raising=False)
     s = small_scene(V=V, HW=40, D=16) if V != 4 else small_scene()
     d = dev_scene(s, dev, ops)
-    blob = d["color_c16_blob"] if mfma == "c16" else (d["color_x3_blob"] if mfma == "x3" else (d["color_mfma_blob"] if mfma else d["color_blob"]))
+    blob = d["color_x3_blob"] if mfma == "x3" else (d["color_mfma_blob"] if mfma else d["color_blob"])
     sc = s["sc"]
     rng = np.random.default_rng(2)
     pts = torch.from_numpy(rng.uniform(-0.9, 0.9, (3000, 3)).astype(np.float32))

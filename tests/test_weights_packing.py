@@ -191,30 +191,3 @@ def test_sdf_grid_tables_are_the_separable_first_layer(pkg):
         got = axes[0][idx[:, 0]].astype(np.float64) + axes[1][idx[:, 1]] + axes[2][idx[:, 2]] + bias
         assert np.abs(got - ref).max() < 5e-6
 
-
-def test_color_c16_blob_emulation_matches_oracle(pkg):
-    """The 16-column formulation of GeneralRenderingNetwork (csrc/color_c16.hip: v_mfma_f32_16x16x32_f16, a point's per-view inputs cached between
-    the two passes), emulated lane by lane from pack_color_c16_blob, vs the oracle network -- incl. a point no view sees and views nobody sees."""
-    from scene_util import color_t
-    sd = pkg.weights.init_color_state_dict(5)
-    rng = np.random.default_rng(3)
-    for k in list(sd):
-        if k.endswith(".bias"):
-            sd[k] = (sd[k] + rng.normal(0, 0.1, sd[k].shape)).astype(np.float32)
-    blob = pkg.weights.pack_color_c16_blob(sd)
-    assert blob.size == pkg.weights.C16_BLOB_FLOATS
-    RW = color_t(sd)
-    for P, V in ((16, 8), (5, 3), (16, 1)):
-        geo = rng.normal(0, 1, (P, 16)).astype(np.float32)
-        rf = rng.normal(0, 1, (P, V, 59)).astype(np.float32)
-        rd = rng.normal(0, 1, (P, V, 4)).astype(np.float32)
-        rd[..., 3] = rng.uniform(-1, 1, (P, V))
-        m = (rng.uniform(0, 1, (P, V)) > 0.3)
-        m[0] = False
-        if V > 2:
-            m[:, 1] = False
-        rf64 = np.concatenate([rf, np.zeros((P, V, 5), np.float32)], -1)
-        got = EMU.emulate_color_c16(blob, geo, rf64, rd, m.astype(np.float32))
-        ref, _ = O.rendering_network(RW, torch.from_numpy(geo), torch.from_numpy(rf).permute(1, 0, 2), torch.from_numpy(rd).permute(1, 0, 2),
-                                     torch.from_numpy(m).permute(1, 0))
-        assert np.abs(got - ref.numpy()).max() < 2e-5, (P, V, np.abs(got - ref.numpy()).max())

@@ -351,108 +351,3 @@ def emulate_color_mfma(blob, geo, rf64, rd, m, G, x3_blob=None):
     return out
 
 
-
-def emulate_color_c16(blob, geo, rf64, rd, m):
-    """Numpy emulation of csrc/color_c16.hip for ONE wave tile (16 points = columns, views walked in two passes), fp64, A operands = hi + lo
-    of pack_color_c16_blob.  geo [P,16], rf64 [P,V,64] (pixel floats: rgb | feat | pad), rd [P,V,4], m [P,V] -> rgb [P,3]."""
-    P, V = rd.shape[:2]
-    assert P <= 16
-    lane = np.arange(64)
-    n, g = lane & 15, lane >> 4
-    nn = np.minimum(n, P - 1)
-
-    def mfma(a8, b8, c):                       # v_mfma_f32_16x16x32_f16: lane supplies k = 8 * (lane >> 4) + t; result rows 4g + i
-        A = np.zeros((16, 32)); B = np.zeros((32, 16))
-        for t in range(8):
-            A[n, 8 * g + t] = a8[:, t]; B[8 * g + t, n] = b8[:, t]
-        D = A @ B
-        out = c.copy()
-        for i in range(4):
-            out[:, i] += D[4 * g + i, n]
-        return out
-
-    def A_of(name):
-        off, nb, ns = C16_LAYOUT["A_" + name]
-        sec = blob[off:off + nb * ns * 512].view(np.float16).reshape(nb, ns, 2, 64, 8).astype(np.float64)
-        return sec[:, :, 0] + sec[:, :, 1]
-
-    def bias_of(name):
-        off, nb = C16_LAYOUT["B_" + name]
-        a = blob[off:off + nb * 16].reshape(nb, 4, 4).astype(np.float64)
-        return [a[b][g] for b in range(nb)]                           # per block [64 lanes][4]
-
-    def layer(name, steps, init=None):
-        """steps: list of [64][8] operand arrays (one per k-step)."""
-        A = A_of(name)
-        acc = [x.copy() for x in (init if init is not None else bias_of(name))]
-        for s, b8 in enumerate(steps):
-            for b in range(len(acc)):
-                acc[b] = mfma(A[b, s], b8, acc[b])
-        return acc
-
-    LG = 1.4426950408889634
-    elu = lambda y: np.maximum(y, LG * (np.minimum(np.exp2(y), 1.0) - 1.0))
-    sig = lambda z: 1 / (1 + np.exp2(-z))
-    pad8 = lambda x4: np.concatenate([x4, np.zeros((64, 8 - x4.shape[1]))], 1)
-    chain = lambda blocks, s=0: np.concatenate([blocks[2 * s], blocks[2 * s + 1]], 1)      # [64][8]: rows of blocks (2s, 2s+1)
-    s_par = float(blob[C16_LAYOUT["SCALAR"][0]])
-    geol = np.stack([geo[nn, 4 * g + t] for t in range(4)], 1).astype(np.float64)        # the lane's 4 geometry channels
-
-    def view_inputs(v):
-        rdl = rd[nn, v].astype(np.float64)
-        xf = np.stack([rf64[nn, v, 16 * g + t] for t in range(16)], 1).astype(np.float64) * LG
-        rgb = rf64[nn, v, :3].astype(np.float64)
-        b0 = np.zeros((64, 8)); b0[g == 0, :4] = rdl[g == 0]
-        d16 = elu(layer("RD0", [b0])[0])
-        dfe = layer("RD1", [pad8(d16)])
-        for b in range(4):
-            xf[:, 4 * b:4 * b + 4] += elu(dfe[b])
-        e = np.exp2(abs(s_par) * LG * (rdl[:, 3] - 1))
-        return rdl, xf, rgb, e
-    emin = np.min(np.stack([view_inputs(v)[3] for v in range(V)]), 0)
-    # pass A: weighted mean / variance over the views (Welford), inputs cached
-    wsum = np.zeros(64); mean = np.zeros((64, 16)); m2 = np.zeros((64, 16)); cache = []
-    for v in range(V):
-        rdl, xf, rgb, e = view_inputs(v)
-        cache.append((rdl, xf, rgb, e))
-        raw = (e - emin) * m[nn, v]
-        wsum = wsum + raw
-        rq = np.where(raw > 0, raw / np.where(wsum > 0, wsum, 1), 0.0)
-        d = xf - mean
-        mean = mean + rq[:, None] * d
-        m2 = m2 + (raw[:, None] * d) * (xf - mean)
-    rden = 1 / (wsum + 1e-8)
-    S = wsum * rden
-    bs = np.concatenate([geol, (S[:, None] * mean), (S * (1 - S) ** 2)[:, None] * mean * mean + m2 * rden[:, None], np.zeros((64, 4))], 1)    # [64][40]
-    sh = layer("S", [bs[:, 8 * s:8 * s + 8] for s in range(5)], init=bias_of("B0"))
-    # pass B
-    smax = np.full(64, -np.inf); ssum = np.zeros(64); o = np.zeros((64, 3))
-    for v in range(V):
-        rdl, xf, rgb, e = cache[v]
-        ml = m[nn, v].astype(np.float64)
-        wgt = (e - emin) * ml * rden
-        h64 = [elu(a) for a in layer("B0", [xf[:, :8], xf[:, 8:]], init=sh)]
-        x32 = [elu(a) for a in layer("B1", [chain(h64, 0), chain(h64, 1)])]
-        t32 = [elu(a) for a in layer("V0", [chain(x32) * wgt[:, None]])]
-        v1 = layer("V1", [chain(t32)])
-        vis = sig(elu(v1[2][:, 0])) * ml
-        x32 = [x32[b] + elu(v1[b]) for b in range(2)]
-        t32 = [elu(a) for a in layer("V20", [chain(x32) * vis[:, None]])]
-        vis2 = sig(layer("V21", [chain(t32)])[0][:, 0]) * ml
-        ex5 = np.zeros((64, 8))
-        sel = g == 0
-        ex5[sel, 0] = vis2[sel]; ex5[sel, 1:5] = rdl[sel]
-        r16 = elu(layer("R0", [chain(x32), ex5])[0])
-        r8 = elu(layer("R1", [pad8(r16)])[0])
-        score = layer("R2", [pad8(r8)])[0][:, 0]
-        score = np.where(ml == 0, -1e9, score)
-        nmax = np.maximum(smax, score)
-        sc_old, ex = np.exp2(smax - nmax), np.exp2(score - nmax)
-        ssum = ssum * sc_old + ex
-        o = o * sc_old[:, None] + ex[:, None] * rgb
-        smax = nmax
-    out = np.zeros((P, 3))
-    for p in range(P):
-        l = np.nonzero((n == p) & (g == 0))[0][0]
-        out[p] = o[l] / ssum[l]
-    return out
