@@ -228,6 +228,20 @@ def pmc_traffic(kernel_prefix):
     return None
 
 
+def pmc_mfma_busy(kernel_prefix):
+    """rocprofv3's matrix-pipe utilisation of a kernel from the committed PMC passes: SQ_VALU_MFMA_BUSY_CYCLES / (active cycles x SIMDs), active cycles =
+    SQ_BUSY_CYCLES / 32 (the counter is summed over the 32 shader engines; it reproduces launch duration x ~2.3 GHz for every kernel of the profile).  This is
+    the "MfmaUtil" the north star asks for; unlike `mfma_pipe_util` (FLOP at the 2.4 GHz peak) it is not diluted by the clock the chip actually sustains."""
+    if PMC_DATA is None:
+        return None
+    for k, v in PMC_DATA.items():
+        if k.startswith(kernel_prefix) and v.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+            active = v["SQ_BUSY_CYCLES"] / 32.0
+            return {"source": PMC_FILE, "kernel": k, "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / (active * 1024.0),
+                    "valu_issue_frac": 4.0 * v.get("SQ_ACTIVE_INST_VALU", 0.0) / (active * 1024.0), "active_cycles": active}
+    return None
+
+
 def pmc_issue_model(kernel_prefix, ms):
     """What the SIMDs of the dominant kernel spend their time on, from the committed PMC passes (profiles/r02_ubench_issue_model.md: a gfx950 SIMD
     issues EITHER vector OR matrix work, so the matrix-pipe utilisation of an issue-bound kernel is MFMA time / (MFMA + VALU time))."""
@@ -504,8 +518,9 @@ def main():
             # points x views / HIP-event time of that launch, against the dense MFMA peak of the type the matrix pipe runs in
             "roofline": dict(rl["color"], traffic=pmc_traffic(COLOR_KERNEL_PREFIX),
                              traffic_source=(f"{PMC_FILE} (bytes, 2*FETCH_SIZE+WRITE_SIZE; collected on these kernel sources)" if PMC_DATA is not None else PMC_STALE),
-                             issue_model=pmc_issue_model(COLOR_KERNEL_PREFIX, kt["color_ms"])),
-            "roofline_sdf": rl["sdf"], "roofline_sdf_grad": rl["sdf_grad"],
+                             issue_model=pmc_issue_model(COLOR_KERNEL_PREFIX, kt["color_ms"]), rocprof=pmc_mfma_busy(COLOR_KERNEL_PREFIX + "<true")),
+            "roofline_sdf": dict(rl["sdf"], rocprof=pmc_mfma_busy("k_sdf_mlp_x3<false>" if wt.sdf_precision == "f16x3" else "k_sdf_mlp<0>")),
+            "roofline_sdf_grad": dict(rl["sdf_grad"], rocprof=pmc_mfma_busy("k_sdf_grad_x3" if wt.sdf_precision == "f16x3" else "k_sdf_mlp<2>")),
             "roofline_costvol": {"kernel": "k_costvol_gather<16>", "bound": "hbm", "achieved": cv_bytes / (kt["costvol_gather_ms"] * 1e-3) / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cv_bytes / (kt["costvol_gather_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": pmc_traffic("k_costvol_gather"), "algorithmic_bytes": cv_bytes, "ms": kt["costvol_gather_ms"]},

@@ -127,6 +127,41 @@ __device__ __forceinline__ void costvol_row_quad16(const float* __restrict__ fea
 #pragma unroll
             for (int k = 0; k < 4; ++k) { idx[k] = tp.idx[k]; w[k] = tp.w[k]; }
         }
+#ifndef O2345_COSTVOL_BATCH
+#define O2345_COSTVOL_BATCH 0      // measured (round 3): 0.166 ms batched vs 0.139 ms one view at a time -- see the comment below and profiles/NOTES.md
+#endif
+#if O2345_COSTVOL_BATCH
+        // A/B form: the taps of the round's four views requested TOGETHER (up to 16 independent 16-byte loads per lane in flight), accumulated afterwards in
+        // the same order (bit-identical sums).  If the kernel were bound by the latency of its dependent gathers this would win; it LOSES (130 registers,
+        // 3 instead of 8 waves per SIMD): the kernel is bound by what the L2 -> L1 path delivers for 64-byte taps, and more waves beat more loads per wave.
+        float4 tv[4][4];
+        float wv[4][4];
+#define O2345_QUAD_LOAD(K)                                                                                             \
+        {                                                                                                              \
+            const float4* base = reinterpret_cast<const float4*>(feats + (size_t)(vb + K < V ? vb + K : 0) * plane * 16) + q;   \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                         \
+                const int ik = quad_bcast_i<K>(idx[k]);                                                                \
+                wv[K][k] = (vb + K < V) ? quad_bcast_f<K>(w[k]) : 0.f;                                                 \
+                tv[K][k] = make_float4(0.f, 0.f, 0.f, 0.f);                                                            \
+                if (wv[K][k] != 0.f) tv[K][k] = base[(size_t)ik * 4];                                                  \
+            }                                                                                                          \
+        }
+        O2345_QUAD_LOAD(0) O2345_QUAD_LOAD(1) O2345_QUAD_LOAD(2) O2345_QUAD_LOAD(3)
+#undef O2345_QUAD_LOAD
+#pragma unroll
+        for (int K = 0; K < 4; ++K)
+            if (vb + K < V) {
+                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (wv[K][k] != 0.f) {
+                        const float4 a = tv[K][k];
+                        f.x += a.x * wv[K][k]; f.y += a.y * wv[K][k]; f.z += a.z * wv[K][k]; f.w += a.w * wv[K][k];
+                    }
+                s1.x += f.x; s1.y += f.y; s1.z += f.z; s1.w += f.w;
+                s2.x += f.x * f.x; s2.y += f.y * f.y; s2.z += f.z * f.z; s2.w += f.w * f.w;
+            }
+#else
 #define O2345_QUAD_VIEW(K)                                                                                             \
         if (vb + K < V) {                                                                                              \
             int ik[4]; float wk[4];                                                                                    \
@@ -135,6 +170,7 @@ __device__ __forceinline__ void costvol_row_quad16(const float* __restrict__ fea
         }
         O2345_QUAD_VIEW(0) O2345_QUAD_VIEW(1) O2345_QUAD_VIEW(2) O2345_QUAD_VIEW(3)
 #undef O2345_QUAD_VIEW
+#endif
     }
     const long long v = ((long long)c.x * g.dy + c.y) * g.dz + c.z;
     const float ic = 1.f / ((float)cnt[v] + 1e-5f);           // sparse_sdf_network.py:242

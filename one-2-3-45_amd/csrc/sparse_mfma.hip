@@ -144,6 +144,117 @@ __global__ __launch_bounds__(LDSW ? 1024 : 256) void k_sparse_conv_x3(const floa
   }
 }
 
+// ---- brick form of the finest same-resolution layer (32 -> 16 channels, MODE 0) ---------------------------------------------------------------
+// The gather form above fetches every neighbour row once per (output row, offset): 27 x per input row, 4 GB of 16-byte-per-lane gathers for
+// 150 MB of rows at 128^3 (0.48 ms, bound by the L1's access rate; profiles/r02_pmc_sparse_conv.json).  Here a workgroup owns a 4 x 4 x 16 brick of
+// lattice sites: it stages the brick's 6 x 6 x 18 halo of input rows in LDS ONCE -- already split into the f16 hi | lo halves the matrix cores
+// consume, so the operand split is also done once per input row instead of 27 times -- and every output site of the brick takes its 27 neighbours
+// from LDS.  D[cout 16][site 16] on v_mfma_f32_16x16x32_f16: a wave owns a z-run of 16 sites (column n = lane & 15), one k step = one neighbour
+// offset x all 32 input channels (lane group g = lane >> 4 supplies channels 8g .. 8g+7: one conflict-free ds_read_b128 per half), three matrix
+// instructions per offset.  The weights are the same blob as above, re-indexed while they are staged (a 16 x 32 A fragment of lane (m, g) is the
+// 32 x 16 fragment of lane m + 32 (g & 1) of channel group g >> 1).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define MFMA16_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+constexpr int BRX = 4, BRY = 4, BRZ = 16, HX = BRX + 2, HY = BRY + 2, HZ = BRZ + 2, HALO = HX * HY * HZ;     // 648 sites
+constexpr int SITE_F = 36;                    // floats per staged site: 16 (hi, 32 f16) + 16 (lo) + 4 pad -> 144-byte stride, conflict-free b128 reads
+constexpr int BRICK_THREADS = 512;
+constexpr int BRICK_W_F = 27 * 2 * 64 * 4;   // weights in LDS: [27][hi|lo][64 lanes][8 f16]
+constexpr size_t BRICK_LDS = (size_t)(BRICK_W_F + HALO * SITE_F) * 4;
+
+__global__ __launch_bounds__(BRICK_THREADS) void k_sparse_conv_brick_32_16(const float* __restrict__ in, const int* __restrict__ grid, Lattice3 lin,
+                                                                            const float* __restrict__ wblob, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;
+    float* hl = lds + BRICK_W_F;
+    {   // weights: dst[(k * 2 + half) * 64 + lane (m, g)] = src[((k * 2 + (g >> 1)) * 2 + half) * 64 + m + 32 * (g & 1)]   (float4 units)
+        const float4* src = reinterpret_cast<const float4*>(wblob);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = threadIdx.x; i < 27 * 2 * 64; i += blockDim.x) {
+            const int l = i & 63, half = (i >> 6) & 1, k = i >> 7;
+            const int m = l & 15, g = l >> 4;
+            dst[i] = (m < 16) ? src[((k * 2 + (g >> 1)) * 2 + half) * 64 + m + 32 * (g & 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float m1 = -1.f;
+    asm volatile("" : "+v"(m1));
+    const int lane = threadIdx.x & 63, n16 = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int nbx = (lin.nx + BRX - 1) / BRX, nby = (lin.ny + BRY - 1) / BRY, nbz = (lin.nz + BRZ - 1) / BRZ;
+    const int nbricks = nbx * nby * nbz;
+    const float4* WL = reinterpret_cast<const float4*>(wl) + lane;
+    for (int brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+        const int bz = brick % nbz, by = (brick / nbz) % nby, bx = brick / (nbz * nby);
+        const int x0 = bx * BRX, y0 = by * BRY, z0 = bz * BRZ;
+        // any occupied output site in the brick?
+        int occ = 0;
+        if (threadIdx.x < BRX * BRY * BRZ) {
+            const int t = threadIdx.x, z = z0 + t % BRZ, y = y0 + (t / BRZ) % BRY, x = x0 + t / (BRZ * BRY);
+            occ = (x < lin.nx && y < lin.ny && z < lin.nz) ? (grid[((size_t)x * lin.ny + y) * lin.nz + z] >= 0) : 0;
+        }
+        if (!__syncthreads_or(occ)) continue;        // (also the barrier that protects the halo buffer of the previous brick)
+        // ---- stage the halo: item = (site, 8-channel chunk); hi | lo halves, zeros for empty / outside sites.  Three batched phases so that the
+        // dependent loads (index grid -> row) of a thread's items are in flight together instead of one item at a time
+        constexpr int NIT = (HALO * 4 + BRICK_THREADS - 1) / BRICK_THREADS;
+        int rr[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int it = threadIdx.x + i * BRICK_THREADS;
+            const int site = it >> 2;
+            const int hz = site % HZ, hy = (site / HZ) % HY, hx = site / (HZ * HY);
+            const int x = x0 + hx - 1, y = y0 + hy - 1, z = z0 + hz - 1;
+            rr[i] = (it < HALO * 4 && x >= 0 && y >= 0 && z >= 0 && x < lin.nx && y < lin.ny && z < lin.nz) ? grid[((size_t)x * lin.ny + y) * lin.nz + z] : -1;
+        }
+        float4 va[NIT], vb[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int c8 = (threadIdx.x + i * BRICK_THREADS) & 3;
+            va[i] = make_float4(0.f, 0.f, 0.f, 0.f); vb[i] = va[i];
+            if (rr[i] >= 0) {
+                const float4* src = reinterpret_cast<const float4*>(in + (size_t)rr[i] * 32) + 2 * c8;
+                va[i] = src[0]; vb[i] = src[1];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int it = threadIdx.x + i * BRICK_THREADS;
+            if (it >= HALO * 4) break;
+            const int site = it >> 2, c8 = it & 3;
+            union { h16x8 v8; h16x2 v2[4]; hh16x2 w2[4]; float4 f4; } bh, bl;
+            const float xv[8] = {va[i].x, va[i].y, va[i].z, va[i].w, vb[i].x, vb[i].y, vb[i].z, vb[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bh.v2[j] = __builtin_amdgcn_cvt_pkrtz(xv[2 * j], xv[2 * j + 1]);
+                bl.v2[j] = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)bh.w2[j][0], m1, xv[2 * j]), __builtin_fmaf((float)bh.w2[j][1], m1, xv[2 * j + 1]));
+            }
+            float4* d = reinterpret_cast<float4*>(hl + site * SITE_F);
+            d[c8] = bh.f4;
+            d[4 + c8] = bl.f4;
+        }
+        __syncthreads();
+        // ---- compute: 16 z-runs, two per wave ---------------------------------------------------------------------------------------------
+        for (int run = wave; run < BRX * BRY; run += BRICK_THREADS / 64) {
+            const int rx = run / BRY, ry = run % BRY;
+            const int x = x0 + rx, y = y0 + ry, z = z0 + n16;
+            const int q = (x < lin.nx && y < lin.ny && z < lin.nz) ? grid[((size_t)x * lin.ny + y) * lin.nz + z] : -1;
+            if (__ballot(q >= 0) == 0ull) continue;
+            f32x4v acc = {0.f, 0.f, 0.f, 0.f}, acc1 = acc, acc2 = acc;      // three independent accumulation chains (the three partial products)
+            // halo coordinates of this lane's site: (rx + 1, ry + 1, n16 + 1); neighbour k adds (ox, oy, oz)
+            const float4* base = reinterpret_cast<const float4*>(hl + (((rx + 1) * HY + (ry + 1)) * HZ + (n16 + 1)) * SITE_F) + g;
+#pragma unroll
+            for (int k = 0; k < 27; ++k) {
+                const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
+                const float4* nb = base + ((ox * HY + oy) * HZ + oz) * (SITE_F / 4);
+                const h16x8 bhi = __builtin_bit_cast(h16x8, nb[0]), blo = __builtin_bit_cast(h16x8, nb[4]);
+                const h16x8 ahi = __builtin_bit_cast(h16x8, WL[(k * 2 + 0) * 64]), alo = __builtin_bit_cast(h16x8, WL[(k * 2 + 1) * 64]);
+                acc1 = MFMA16_F16(alo, bhi, acc1);
+                acc2 = MFMA16_F16(ahi, blo, acc2);
+                acc = MFMA16_F16(ahi, bhi, acc);
+            }
+            acc += acc1 + acc2;
+            if (q >= 0) *reinterpret_cast<float4*>(out + (size_t)q * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+}
+
 }  // namespace o2345
 
 using namespace o2345;
@@ -180,6 +291,16 @@ int o2345_sparse_conv3d_x3(int mode, const float* in, int cin, const int32_t* in
     const int n_cu = cu_count();
     const unsigned want = cdiv(n_out, 32 * 16);                       // 16 tiles (waves) per persistent workgroup round
     dim3 pgrid(want < (unsigned)n_cu ? want : (unsigned)n_cu);
+    {
+        // finest same-resolution layer: LDS-tiled brick form (O2345_SPARSE_BRICK=0 keeps the gather form: A/B runs)
+        const char* e = getenv("O2345_SPARSE_BRICK");
+        if (mode == 0 && cin == 32 && cout == 16 && !(e && e[0] == '0')) {
+            const int nbricks = ((gx + BRX - 1) / BRX) * ((gy + BRY - 1) / BRY) * ((gz + BRZ - 1) / BRZ);
+            O2345_HIP(hipFuncSetAttribute((const void*)k_sparse_conv_brick_32_16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BRICK_LDS));
+            hipLaunchKernelGGL(k_sparse_conv_brick_32_16, dim3(nbricks < n_cu ? nbricks : n_cu), dim3(BRICK_THREADS), BRICK_LDS, s, in, in_grid, lin, wblob, out);
+            return check_launch("sparse_conv3d_x3 (brick form)");
+        }
+    }
     O2345_CONVX_CASE(32, 16) O2345_CONVX_CASE(16, 16) O2345_CONVX_CASE(16, 32) O2345_CONVX_CASE(32, 32)
     O2345_CONVX_CASE(32, 64) O2345_CONVX_CASE(64, 64) O2345_CONVX_CASE(64, 32) O2345_CONVX_CASE(48, 16)
     O2345_REQUIRE(false, "sparse_conv3d_x3: unsupported channels %d -> %d", cin, cout);

@@ -95,7 +95,9 @@ def test_sparse_cnn_and_scatter(dev, ops, precision):
 
 @pytest.mark.parametrize("cin,cout,mode", [(32, 16, 0), (16, 32, 1), (64, 64, 0), (64, 32, 2), (48, 16, 0), (32, 64, 1), (16, 16, 2)])
 def test_sparse_conv_x3_single_layer(dev, ops, cin, cout, mode):
-    """One layer of csrc/sparse_mfma.hip against the fp32 VALU kernel on a random sparse set (incl. a ragged last tile)."""
+    """One layer of csrc/sparse_mfma.hip (and of the fp32 VALU kernel) against the ORACLE's sparse convolution (oracle.sparse_conv over oracle.build_kmap,
+    torchsparse v1.4.0 semantics) on a random sparse set incl. a ragged last tile -- every (cin, cout, mode) the two lod networks use, (48, 16) = the lod-1
+    input width included."""
     Wn = importlib.import_module("one-2-3-45_amd.weights")
     rng = np.random.default_rng(cin * 100 + cout + mode)
     D = 24
@@ -119,6 +121,14 @@ def test_sparse_conv_x3_single_layer(dev, ops, cin, cout, mode):
     ref = ops.sparse_conv3d(mode, *args, K)
     got = ops.sparse_conv3d_x3(mode, *args, blob, cout)
     close(got, ref, rel=2e-5, what=f"sparse conv x3 {cin}->{cout} mode {mode}")
+    # the oracle: level objects + kernel maps of oracle/recon.py (down: outputs on the coarse level; up: the down map with roles swapped)
+    L0 = O.SparseLevel(torch.from_numpy(xyz).long(), 1)
+    L1 = O.downsample_coords(L0)
+    assert torch.equal(L1.xyz, co1[:, :3].cpu().long())
+    kmap = O.build_kmap(L0, L0) if mode == 0 else O.build_kmap(L0, L1)
+    want = O.sparse_conv(x.cpu(), kmap, K.cpu(), transposed=(mode == 2), n_out=len(xyz) if mode == 2 else None)
+    close(got, want, rel=2e-5, what=f"sparse conv x3 vs oracle {cin}->{cout} mode {mode}")
+    close(ref, want, rel=2e-5, what=f"sparse conv fp32 vs oracle {cin}->{cout} mode {mode}")
 
 
 def test_bn_and_abn(dev, ops):
