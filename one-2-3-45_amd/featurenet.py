@@ -23,7 +23,7 @@ def packed_weight(conv, precision=None):
 def invalidate_packed(module):
     """Drop every cached weight packing below ``module`` (after parameter updates through ``.data``, which no version counter sees)."""
     for m in module.modules():
-        for attr in ("_o2345_packed_key", "_blob_key"):
+        for attr in ("_o2345_packed_key", "_blob_key", "_key", "_costreg_key"):      # conv packings, SDF blob, colour blobs, packed sparse CNN
             if hasattr(m, attr):
                 setattr(m, attr, None)
 

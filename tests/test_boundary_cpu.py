@@ -126,3 +126,23 @@ def test_precision_config(pkg, monkeypatch):
     for name, ci, co in W.COSTREG_LAYERS:
         K = cs[f"{name}.net.0.kernel"]
         assert W.pack_sparse_conv_x3(K).size == L.o2345_sparse_conv_x3_blob_floats(K.shape[1], K.shape[2])
+
+
+def test_invalidate_packed_drops_every_weight_cache():
+    """Parameter updates through `.data` (EMA, weight surgery) bump no version counter: featurenet.invalidate_packed is the documented hook.  It must
+    reset the cache key of every module that keeps packed operands (conv packings, SDF blob, colour blobs, packed sparse CNN)."""
+    import importlib
+    import torch
+    fn = importlib.import_module("one-2-3-45_amd.featurenet")
+    sdfm = importlib.import_module("one-2-3-45_amd.recon.sparse_sdf_network")
+    renm = importlib.import_module("one-2-3-45_amd.recon.rendering_network")
+    net = torch.nn.ModuleList([fn.FeatureNet(), sdfm.SparseSdfNetwork(lod=0, ch_in=56, voxel_size=0.1, vol_dims=[8, 8, 8], regnet_d_out=16),
+                               renm.GeneralRenderingNetwork(in_geometry_feat_ch=16)])
+    keys = ("_o2345_packed_key", "_blob_key", "_key", "_costreg_key")
+    for m in net.modules():
+        for k in keys:
+            if hasattr(m, k):
+                setattr(m, k, ("stale",))
+    net[0].conv0[0].conv._o2345_packed_key = ("stale",)
+    fn.invalidate_packed(net)
+    assert all(getattr(m, k, None) is None for m in net.modules() for k in keys)
