@@ -635,3 +635,45 @@ def test_convolution_precision_is_per_object(dev, ops, monkeypatch):
     monkeypatch.setattr(config, "PRECISION", "f16x3")
     wt = pipeline.SceneWeights(dev, seed=0, color_precision="fp32")
     assert wt.featurenet.precision == "fp32" and wt.compress.precision == "fp32" and all(m.precision == "fp32" for m in wt.featurenet.modules() if isinstance(m, fn.ConvBnReLU))
+
+
+@pytest.mark.parametrize("V", [5, 8, 32])
+def test_view_skipping_is_bit_identical(dev, ops, V, monkeypatch):
+    """k_color_pts skips the views that see none of a tile's 32 points (wave-uniform).  The claim is BIT-identity with the kernel that evaluates every
+    view (O2345_COLOR_SCHED bit 2), for colours and valid-view counts, on a point set that contains every case: points seen by many views, by one, by
+    none (all-masked tiles blend every view uniformly), points outside the volume, tiles whose points disagree about a view, a ragged last tile."""
+    s = small_scene(V=V, HW=40, D=16) if V != 4 else small_scene()
+    d = dev_scene(s, dev, ops)
+    sc = s["sc"]
+    rng = np.random.default_rng(V)
+    # tiles of the render path are 32 neighbouring points: clusters of 32 around random centres (coherent visibility), some tiles of unrelated points
+    centres = rng.uniform(-0.95, 0.95, (128, 3)).astype(np.float32)
+    centres[:8] = rng.uniform(0.8, 0.99, (8, 3)).astype(np.float32) * np.sign(rng.standard_normal((8, 3))).astype(np.float32)      # corners: few / no views
+    pts = (centres[:, None] + rng.normal(0, 2e-3, (128, 32, 3)).astype(np.float32)).reshape(-1, 3)
+    pts[64:96] = np.array([1.5, 0.0, 0.0], np.float32)                                                                            # a whole tile outside
+    pts[1024:1280] = rng.uniform(-0.95, 0.95, (256, 3)).astype(np.float32)                                                        # incoherent tiles
+    pts = np.concatenate([pts, rng.uniform(-0.5, 0.5, (3, 3)).astype(np.float32)])                                               # ragged last tile
+    p = torch.from_numpy(pts).to(dev)
+    qcam = torch.from_numpy(sc["query_c2w"][:3, 3].copy()).to(dev)
+    monkeypatch.delenv("O2345_COLOR_KERNEL", raising=False)
+    outs = {}
+    for sched in ("4", "0", "10", "14"):
+        monkeypatch.setenv("O2345_COLOR_SCHED", sched)
+        ops.color_stats(True)
+        outs[sched] = ops.color_points(d["color_x3_blob"], d["vol_cl"], d["maskvol"], d["cmaps"], d["proj"], d["cam_pos"], p, query_cam=qcam, mfma="x3")
+        outs[sched] += (ops.color_stats_read(),)
+        ops.color_stats(False)
+    ref = outs["4"]
+    assert ref[2]["pairs_network"] == ref[2]["tiles"] * V                      # bit 2: every (tile, view) pair evaluated
+    for k in ("0", "10"):
+        assert torch.equal(outs[k][0], ref[0]) and torch.equal(outs[k][1], ref[1]), k
+        assert outs[k][2]["pairs_network"] < ref[2]["pairs_network"] and outs[k][2]["pairs_pooling"] < ref[2]["pairs_pooling"]   # something WAS skipped
+    assert torch.equal(outs["14"][0], ref[0])
+    assert int((ref[1] == 0).sum()) >= 32 and int((ref[1] >= 2).sum()) > 500
+    # and against the oracle (colours of the no-visible-view points included)
+    Kt, w2c = torch.from_numpy(sc["intrinsics"]), torch.from_numpy(sc["w2cs"])
+    geo, rf, rdf, vm = O.projector(torch.from_numpy(pts), s["dense"][0], s["mask"][0, 0], torch.from_numpy(s["fmaps"]), torch.from_numpy(sc["images"]), w2c, Kt,
+                                   (s["W"], s["H"]), query_cam=qcam.cpu())
+    rgb_ref, nv_ref = O.rendering_network(color_t(s["color_sd"]), geo, rf, rdf, vm)
+    assert torch.equal(ref[1].cpu().float(), nv_ref)
+    close(outs["10"][0], rgb_ref, rel=1e-4, what="blended colour with view skipping")
