@@ -20,7 +20,7 @@ N > 1: one process per GPU, every rank reconstructs its own scenes: embarrassing
 Besides the contract's line (config 2), rank 0 attaches: `parity_fullsize` (the cpu_baseline rays compared with the HIP outputs),
 `c3` (BASELINE config 3: 32 distinct scenes dealt over the ranks, inputs uploaded host->device inside the step), `ref_config`
 (the reference's own V=32 / 96^3 / 256^3 configuration), `config5` (256^3 volume, 1024^2 rays, 512^3 grid), `fp32_whole_step_ms`,
-`roofline_bf16_mode`, `cpu_baseline_reference` (the reference's own modules timed in the build container).  `--quick` skips them.
+`cpu_baseline_reference` (the reference's own modules timed in the build container).  `--quick` skips them.
 """
 import argparse
 import importlib
@@ -44,11 +44,11 @@ config = importlib.import_module("one-2-3-45_amd.config")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3      # v_mfma_f32_32x32x2_f32 = fp32 vector rate
 F16_MFMA_PEAK_TF = 2516.6      # v_mfma_f32_32x32x16_f16 / bf16, dense (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
-MFMA_PEAK = {"fp32": FP32_MFMA_PEAK_TF, "f16x3": F16_MFMA_PEAK_TF, "bf16": F16_MFMA_PEAK_TF}
+MFMA_PEAK = {"fp32": FP32_MFMA_PEAK_TF, "f16x3": F16_MFMA_PEAK_TF}
 # FLOP the matrix pipe actually executes per unit (padding and, for f16x3, the three partial products included)
 COLOR_MFMA_FLOP_PER_PAIR = {"fp32": 189 * 32 * 32 * 2 * 2 / 32, "f16x3": 75 * 32 * 32 * 16 * 2 / 32}
-SDF_MFMA_FLOP_PER_POINT = {"fp32": 368 * 4096 / 32, "f16x3": 144 * 32768 / 32, "bf16": (80 * 4096 + 36 * 32768) / 32}
-GRAD_MFMA_FLOP_PER_POINT = {"fp32": 896 * 4096 / 32, "f16x3": 348 * 32768 / 32, "bf16": (160 * 4096 + 92 * 32768) / 32}
+SDF_MFMA_FLOP_PER_POINT = {"fp32": 368 * 4096 / 32, "f16x3": 144 * 32768 / 32}
+GRAD_MFMA_FLOP_PER_POINT = {"fp32": 896 * 4096 / 32, "f16x3": 348 * 32768 / 32}
 # algorithmic FLOP per unit
 SDF_FLOP_SDF_ONLY = 2 * (39 * 128 + 144 * 128 + 144)            # 47,136 per point (SDF-only forward)
 SDF_FLOP_GRAD = 2 * SDF_FLOP_SDF_ONLY                          # + ~47,136 for the input gradient (transposed GEMMs)
@@ -182,7 +182,7 @@ def network_rooflines(kt, V, sdf_p, col_p):
     cw = kt["color_work"]
     na, nb_, nt, fl = COLOR_PTS_MFMA[col_p]
     color_pipe_flop = (na * cw["pairs_pooling"] + nb_ * cw["pairs_network"] + nt * cw["tiles"]) * fl        # what the matrix pipe executed in that launch
-    sname = {"fp32": ("k_sdf_mlp<0>", "k_sdf_mlp<2>"), "f16x3": ("k_sdf_mlp_x3", "k_sdf_grad_x3"), "bf16": ("k_sdf_mlp_bf16<0>", "k_sdf_mlp_bf16<2>")}[sdf_p]
+    sname = {"fp32": ("k_sdf_mlp<0>", "k_sdf_mlp<2>"), "f16x3": ("k_sdf_mlp_x3", "k_sdf_grad_x3")}[sdf_p]
     return {
         "color": blk(cname + ": Projector + GeneralRenderingNetwork", nvp * V, COLOR_FLOP_PER_PAIR, color_pipe_flop / max(1, nvp * V),
                      kt["color_ms"], MFMA_PEAK[col_p],
@@ -398,14 +398,14 @@ def main():
     ap.add_argument("--ray-chunk", type=int, default=1 << 18)
     ap.add_argument("--cpu-rays", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--quick", action="store_true", help="only the contract's line (no c3 / ref_config / config5 / fp32 / bf16 blocks)")
+    ap.add_argument("--quick", action="store_true", help="only the contract's line (no c3 / ref_config / config5 / fp32 blocks)")
     ap.add_argument("--same-scene", action="store_true", help="re-reconstruct one scene every step (round-1 behaviour; A/B knob)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for the CPU plumbing test)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous + sharding only, no GPU work (CPU plumbing test)")
     ap.add_argument("--share-gpu", action="store_true", help="FUNCTIONAL TEST ONLY: ranks may share a device (rank r on cuda:r mod count; use with "
                                                              "--backend gloo, RCCL refuses duplicate devices).  The number it prints is not a scaling measurement")
     ap.add_argument("--precision", choices=config.PRECISIONS, default=config.PRECISION,
-                    help="network kernels: f16x3 (default; split-f16 MFMA, fp32-class accuracy), fp32 (exact fp32 MFMA), bf16 (SDF throughput mode)")
+                    help="network kernels: f16x3 (default; split-f16 MFMA, fp32-class accuracy), fp32 (exact fp32 MFMA)")
     ap.add_argument("--ckpt", default=None, help="checkpoint in the reference's format (exp_runner...:514-541); default: seeded stand-in weights, identical on every rank")
     ap.add_argument("--broadcast-weights", action="store_true", help="with --ckpt: rank 0 reads the file, ONE RCCL broadcast hands the weights to the other ranks "
                                                                       "(the north star's optional shared-backbone broadcast); default: every rank reads the file")
@@ -495,8 +495,7 @@ def main():
         cv_bytes = V * C * 256 * 256 * 4 + n_vox * (2 * C * 4 + 16) + a.vol ** 3
         nvp, npts = kt["n_valid_points"], kt["n_points"]
         rl = network_rooflines(kt, V, wt.sdf_precision, wt.color_precision)
-        dtype = {"f16x3": "f32 (matrix products as 3 f16 MFMAs on split operands, fp32 accumulate)", "fp32": "f32",
-                 "bf16": "f32; SDF wide layers bf16 operands with fp32 accumulate"}[a.precision]
+        dtype = {"f16x3": "f32 (matrix products as 3 f16 MFMAs on split operands, fp32 accumulate)", "fp32": "f32"}[a.precision]
         result = {
             "metric": "rays/sec + mesh-extract wall-clock per scene (8x256^2 views, 128^3 vol)", "value": world * n_rays / (ms_step * 1e-3),
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -531,11 +530,6 @@ def main():
             # the same three kernels in the exact fp32 MFMA form, priced against the fp32 matrix peak (strict mode of the library)
             kf = kernel_times(wt, vol, inp, outs, a.vol, reps=3, sdf_precision="fp32", color_precision="fp32")
             result["roofline_fp32_mode"] = network_rooflines(kf, V, "fp32", "fp32")
-        if a.precision != "bf16" and not a.quick:
-            # BASELINE config 2's wording ("bf16 SDF MLP"): the SDF kernels in the bf16 throughput mode (opt-in: 3e-3 SDF error)
-            kb = kernel_times(wt, vol, inp, outs, a.vol, reps=3, sdf_precision="bf16", color_precision="f16x3")
-            rb = network_rooflines(kb, V, "bf16", "f16x3")
-            result["roofline_bf16_mode"] = {"sdf": rb["sdf"], "sdf_grad": rb["sdf_grad"]}
         if world == 1 and not a.no_cpu:
             vol0 = pipeline.build_volume(wt, inp["imgs"], inp["aff"], inp["origin"], a.vol, 2.0 / (a.vol - 1))     # the scene cpu_baseline's images belong to
             result["cpu_baseline"], result["parity_fullsize"] = cpu_baseline_and_parity(wt, vol0, inp, a.vol, a.cpu_rays)

@@ -145,11 +145,6 @@ int o2345_sdf_mlp(int variant, const float* blob, const float* vol_cl, int D, co
 int o2345_sdf_mlp_ex(int variant, const float* blob, const float* vol_cl, int D, const float* pts, const int32_t* index,
                      const int32_t* n_dev, long long n, int grid_R, float sign, const float* lat_in, float* out_sdf,
                      float* out_feat, float* out_lat, float* out_grad, void* stream);
-/* throughput mode of the same network (BASELINE config 2 "bf16 SDF MLP"): layer 0 and the output row stay
- * fp32, the 144->128 layer and both backward GEMMs take bf16 operands with fp32 accumulation.  variant 0 or 2 only.
- * Tolerance-based parity (|d sdf| <= 2e-2 * max|sdf| stated in tests/test_gpu_parity.py); never the default. */
-int o2345_sdf_mlp_bf16(int variant, const float* blob, const float* vol_cl, int D, const float* pts, const int32_t* index,
-                       const int32_t* n_dev, long long n, int grid_R, float sign, float* out_sdf, float* out_grad, void* stream);
 /* fp32-class accuracy on the f16 matrix cores: every operand split into two f16 halves (hi + lo, 22 bits) and each product
  * accumulated in fp32 as hi*hi + hi*lo + lo*hi -- three v_mfma_f32_32x32x16_f16 instead of eight fp32 MFMAs per 16 k.
  * Same function as o2345_sdf_mlp variant 0 within ~1e-6 (tests/test_gpu_parity.py::test_sdf_mlp_x3). */
@@ -202,7 +197,7 @@ typedef struct O2345RenderIO {
     float* color; float* depth; float* weights; float* cdf; float* weights_sum; float* weights_max; float* depth_var;
     float* alpha_sum; float* grad_err; uint8_t* color_mask; float* z_vals;
     const float* color_mfma_blob;   /* optional: use the fp32 matrix-core colour kernels */
-    int sdf_bf16;                   /* SDF network mode: 0 exact fp32 MFMA; 1 bf16 throughput mode; 2 split-f16 ("f16x3", fp32-class
+    int sdf_bf16;                   /* SDF network mode: 0 exact fp32 MFMA; 2 split-f16 ("f16x3", fp32-class
                                      * accuracy: o2345_sdf_mlp_x3 / o2345_sdf_grad_x3) */
     const float* color_x3_blob;     /* optional: split-f16 colour kernels (take precedence over color_mfma_blob) */
     const float* t_rand;            /* optional [R][n_samples]: the reference's perturb > 0 jitter, drawn by the caller (ABI 1.2) */

@@ -7,11 +7,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libo2345_hip.so")
-SOURCES = ["api.cpp", "costvol.hip", "sparse.hip", "sparse_mfma.hip", "sdf_mlp.hip", "sdf_mlp_bf16.hip", "sdf_mlp_x3.hip", "render.hip", "color.hip", "color_mfma.hip", "color_pts.hip", "mcubes.hip", "mesh_pack.hip", "featmaps.hip", "convnet.hip"]
+SOURCES = ["api.cpp", "costvol.hip", "sparse.hip", "sparse_mfma.hip", "sdf_mlp.hip", "sdf_mlp_x3.hip", "render.hip", "color.hip", "color_mfma.hip", "color_pts.hip", "mcubes.hip", "mesh_pack.hip", "featmaps.hip", "convnet.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default"]
 # The network kernels are VALU-bound and take max(x, .) of raw MFMA accumulators hundreds of times per tile; under IEEE NaN
 # rules every such max is preceded by a quieting v_max x,x,x.  Their inputs are finite by construction.
-EXTRA_FLAGS = {name: ["-fno-honor-nans"] for name in ("sdf_mlp.hip", "sdf_mlp_bf16.hip", "sdf_mlp_x3.hip", "color_mfma.hip", "color_pts.hip")}
+EXTRA_FLAGS = {name: ["-fno-honor-nans"] for name in ("sdf_mlp.hip", "sdf_mlp_x3.hip", "color_mfma.hip", "color_pts.hip")}
 
 
 def sources_sha():

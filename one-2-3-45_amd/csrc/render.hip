@@ -150,8 +150,6 @@ extern "C" {
 int o2345_sdf_mlp(int variant, const float* blob, const float* vol_cl, int D, const float* pts, const int32_t* index,
                   const int32_t* n_dev, long long n, int grid_R, float sign, float* out_sdf, float* out_feat,
                   float* out_lat, float* out_grad, void* stream);
-int o2345_sdf_mlp_bf16(int variant, const float* blob, const float* vol_cl, int D, const float* pts, const int32_t* index,
-                       const int32_t* n_dev, long long n, int grid_R, float sign, float* out_sdf, float* out_grad, void* stream);
 int o2345_sdf_mlp_x3(const float* blob, const float* vol_cl, int D, const float* pts, const int32_t* index, const int32_t* n_dev,
                      long long n, int grid_R, float sign, float* out_sdf, void* stream);
 int o2345_sdf_grad_x3(const float* blob, const float* vol_cl, int D, const float* pts, const int32_t* index, const int32_t* n_dev,
@@ -255,7 +253,7 @@ struct O2345RenderIO {
     float* color; float* depth; float* weights; float* cdf; float* weights_sum; float* weights_max; float* depth_var;
     float* alpha_sum; float* grad_err; uint8_t* color_mask; float* z_vals;
     const float* color_mfma_blob;
-    int sdf_bf16;               // SDF network mode: 0 fp32 MFMA, 1 bf16 (sdf_mlp_bf16.hip), 2 split-f16 forward (sdf_mlp_x3.hip)
+    int sdf_bf16;               // SDF network mode: 0 fp32 MFMA, 2 split-f16 (sdf_mlp_x3.hip).  (1 was the bf16 mode removed in round 3; the field keeps its name: ABI)
     const float* color_x3_blob; // optional: split-f16 colour kernel
     const float* t_rand;        // optional [R][n_samples]: stratified jitter of the coarse samples (perturb > 0)
 };
@@ -278,12 +276,11 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     int* count = list + S * RR;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    const bool hb = io->sdf_bf16 == 1;
+    O2345_REQUIRE(io->sdf_bf16 == 0 || io->sdf_bf16 == 2, "render_rays: SDF mode %d (0 = fp32, 2 = split-f16; the bf16 mode was removed)", io->sdf_bf16);
     auto sdf_eval = [&](int variant, const float* p, const int* idx, const int* cnt, long long n, float* out, float* grad) {
         if (io->sdf_bf16 == 2 && variant == 0) return o2345_sdf_mlp_x3(io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, stream);
         if (io->sdf_bf16 == 2 && variant == 2) return o2345_sdf_grad_x3(io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, grad, stream);
-        return hb ? o2345_sdf_mlp_bf16(variant, io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, grad, stream)
-                  : o2345_sdf_mlp(variant, io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, nullptr, nullptr, grad, stream);
+        return o2345_sdf_mlp(variant, io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, nullptr, nullptr, grad, stream);
     };
     if ((rc = o2345_ray_coarse_jitter(io->rays_o, io->rays_d, R, io->near, io->far, NS, io->t_rand, z, pts, stream))) return rc;
     // coarse SDF on ALL points (not masked, :525-528)

@@ -1,5 +1,4 @@
-// Shared pieces of the SDF-network kernels (csrc/sdf_mlp.hip: exact fp32 MFMA; csrc/sdf_mlp_bf16.hip: bf16 operands for the
-// wide layers): blob geometry, argument block, softplus, ATen-exact linspace, A-operand fetch and the pinned MFMA step loop.
+// Shared pieces of the SDF-network kernels (csrc/sdf_mlp.hip: exact fp32 MFMA; csrc/sdf_mlp_x3.hip: split-f16 operands): blob geometry, argument block, softplus, ATen-exact linspace, A-operand fetch and the pinned MFMA step loop.
 #pragma once
 #include "common.h"
 #include "geom_math.h"
@@ -21,7 +20,7 @@ constexpr int OFF_A0T = OFF_A1T + 5 * STB * 64;    // [2][STB][64]   d/d(pe)
 constexpr int OFF_MISC = OFF_A0T + 2 * STB * 64;   // b0[128] b1[128] b2[128] w2row_h[128] w2row_lat[16] (lane-half order)
 constexpr int MISC_B0 = 0, MISC_B1 = 128, MISC_B2 = 256, MISC_W2H = 384, MISC_W2L = 512, MISC_SIZE = 528;
 constexpr int BLOB_F32_FLOATS = OFF_MISC + MISC_SIZE;
-// bf16 copies of the wide-layer operands for csrc/sdf_mlp_bf16.hip: [block][step][64 lanes][8 bf16 = 4 floats]
+// reserved section (the bf16 operand copies of the bf16 mode removed in round 3): [block][step][64 lanes][4 floats]; the split-f16 offsets follow it
 constexpr int STH1 = 9;                                  // layer-1 k steps of 16 (8 hidden + 1 latent)
 constexpr int STHB = 8;                                  // backward k steps of 16 (128 upstream neurons)
 constexpr int OFFH_A1 = BLOB_F32_FLOATS;                 // [4][STH1][64][4]

@@ -8,7 +8,7 @@
 // results (the fp32 MFMA chain itself carries ~1e-7).  Weights are split on the host (weights.pack_sdf_blob), activations
 // in registers: hi = f16(x) rounded toward zero, lo = f16(x - hi) with the exact difference from one v_fma_mix_f32:
 // 2 VALU instructions per value.  Domain: |x| < 65504 (activations here are O(1)).
-// Lane layout, blob order and the register chaining between layers are those of csrc/sdf_mlp_bf16.hip.
+// Lane layout, blob order and the register chaining between layers: two wave halves supply 8 k values each of a 16-k step (weights.kcol_h / neuron_of).
 #include "sdf_common.h"
 
 namespace o2345 {

@@ -356,13 +356,10 @@ def sdf_grid_tables(tab_axes, bias_lane_order):
 def sdf_mlp(blob, vol_cl, pts=None, variant=0, grid_R=0, sign=1.0, index=None, n_dev=None, want_lat=False, out=None, lat_in=None,
             precision=None, grid_tables=None):
     """variant 0: sdf; 1: sdf + 128 features; 2: sdf + gradient.  pts [P,3] or grid_R.  lat_in [P,16]: given latents instead of
-    sampling the volume (get_sdf_volume).  precision "bf16": throughput mode (variants 0/2); "f16x3": split-f16 MFMA at fp32-class accuracy
-    (variants 0 and 2; variant 1 / lat_in fall back to the fp32 kernel).  grid_tables (f16x3, variant 0, lattice mode): (tab_xy, tab_z) from
+    sampling the volume (get_sdf_volume).  precision "f16x3" (default): split-f16 MFMA at fp32-class accuracy (variants 0 and 2; variant 1 / lat_in
+    run on the fp32 kernel); "fp32": the exact fp32 MFMA kernels.  grid_tables (f16x3, variant 0, lattice mode): (tab_xy, tab_z) from
     ops.sdf_grid_tables -- layer 0 read from per-axis tables instead of being evaluated per point.  Returns dict of tensors."""
-    implicit = precision is None
     precision = config.sdf_precision(precision)
-    if implicit and precision == "bf16" and (variant == 1 or want_lat or lat_in is not None):
-        precision = "f16x3"                    # the throughput mode has no 128-feature / given-latent form
     D = vol_cl.shape[0]
     dev = vol_cl.device
     if pts is not None:
@@ -395,12 +392,6 @@ def sdf_mlp(blob, vol_cl, pts=None, variant=0, grid_R=0, sign=1.0, index=None, n
     if precision == "f16x3" and variant == 2 and not want_lat and lat_in is None:
         check(_lib.lib().o2345_sdf_grad_x3(_p(blob), _p(vol_cl), D, _p(pts), _p(index, torch.int32), _p(n_dev, torch.int32), n, int(grid_R),
                                            float(sign), _p(res["sdf"]), _p(res["grad"]), _stream()), "sdf_grad_x3")
-        return res
-    if precision == "bf16":
-        if variant == 1 or want_lat or lat_in is not None:
-            raise ValueError("sdf_mlp: the bf16 mode covers variants 0 and 2 on the sampled volume only")
-        check(_lib.lib().o2345_sdf_mlp_bf16(int(variant), _p(blob), _p(vol_cl), D, _p(pts), _p(index, torch.int32), _p(n_dev, torch.int32),
-                                            n, int(grid_R), float(sign), _p(res["sdf"]), _p(res.get("grad")), _stream()), "sdf_mlp_bf16")
         return res
     check(_lib.lib().o2345_sdf_mlp_ex(int(variant), _p(blob), _p(vol_cl), D, _p(pts), _p(index, torch.int32), _p(n_dev, torch.int32),
                                       n, int(grid_R), float(sign), _p(lat_in), _p(res["sdf"]), _p(res.get("feat")), _p(res.get("lat")),
@@ -534,7 +525,7 @@ def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64,
     use_x3 = scene.get("color_x3_blob") is not None and config.color_precision(scene.get("color_precision")) == "f16x3"
     io.color_x3_blob = _p(scene["color_x3_blob"]).value if use_x3 else None
     io.t_rand = _p(t_rand).value if t_rand is not None else None
-    io.sdf_bf16 = {"fp32": 0, "bf16": 1, "f16x3": 2}[config.sdf_precision(scene.get("sdf_precision"))]
+    io.sdf_bf16 = {"fp32": 0, "f16x3": 2}[config.sdf_precision(scene.get("sdf_precision"))]
     io.D, io.V, io.H, io.W = scene["vol_cl"].shape[0], V, H, W
     io.rays_o, io.rays_d, io.R = _p(rays_o).value, _p(rays_d).value, R
     io.near, io.far, io.n_samples, io.n_importance = float(near), float(far), n_samples, n_importance

@@ -27,7 +27,7 @@ class SceneWeights:
         sdf_precision = config.sdf_precision(sdf_precision)
         color_precision = config.color_precision(color_precision)
         self.color_precision = color_precision    # "f16x3" (default) | "fp32": see config.py
-        self.sdf_precision = sdf_precision        # "f16x3" (default) | "fp32" | "bf16": see config.py
+        self.sdf_precision = sdf_precision        # "f16x3" (default) | "fp32": see config.py
         with torch.random.fork_rng(devices=[]):         # seeded stand-in initialisation must not reset the caller's global RNG
             torch.manual_seed(seed)
             self.featurenet = set_precision(FeatureNet().to(device), color_precision)      # 2-D convolutions follow the same mode as the

@@ -20,7 +20,7 @@ OFF_A0T = OFF_A1T + 5 * STB * 64
 OFF_MISC = OFF_A0T + 2 * STB * 64
 MISC_B0, MISC_B1, MISC_B2, MISC_W2H, MISC_W2L, MISC_SIZE = 0, 128, 256, 384, 512, 528
 SDF_F32_FLOATS = OFF_MISC + MISC_SIZE
-# bf16 copies of the wide-layer operands (csrc/sdf_mlp_bf16.hip): [block][k-step of 16][64 lanes][8 bf16 = 4 floats]
+# reserved: former bf16 copies of the wide-layer operands ([block][k-step of 16][64 lanes][8 bf16 = 4 floats]); the offsets of the split-f16 sections depend on it
 STH1, STHB = 9, 8
 OFFH_A1 = SDF_F32_FLOATS
 OFFH_A1T = OFFH_A1 + 4 * STH1 * 64 * 4
@@ -55,16 +55,6 @@ def f16_split_device(x):
         return h.astype(np.float32)
     hi = rtz(x)
     return hi, rtz(x - hi)
-
-
-def bf16_round(x):
-    """fp32 -> bf16 bit patterns (uint16), round-to-nearest-even (what v_cvt_pk_bf16_f32 does)."""
-    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
-    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
-
-
-def bf16_to_f32(b):
-    return (np.asarray(b, np.uint16).astype(np.uint32) << 16).view(np.float32)
 
 
 def kcol_h(s, h, t):
@@ -189,10 +179,7 @@ def pack_sdf_blob(W):
             for ob in range(2):
                 cols = np.array([pe_index(int(ob * 16 + r), int(h)) if ob * 16 + r < 20 else -1 for r, h in zip(r_row, h_row)])
                 F_A0T[ob, st, :, t] = np.where(cols >= 0, w0[n, np.maximum(cols, 0)], 0.0)
-    halves = blob[OFFH_A1:SDF_BF16_END].view(np.uint16)
-    halves[:4 * STH1 * 512] = bf16_round(F_A1).ravel()
-    halves[(OFFH_A1T - OFFH_A1) * 2:(OFFH_A0T - OFFH_A1) * 2] = bf16_round(F_A1T).ravel()
-    halves[(OFFH_A0T - OFFH_A1) * 2:] = bf16_round(F_A0T).ravel()
+    # floats OFFH_A1 .. SDF_BF16_END are reserved (they held the bf16 operand copies of the removed bf16 mode; the split-f16 sections keep their offsets)
     for off, F in ((OFFX_A0, F_A0), (OFFX_A1, F_A1), (OFFX_A1T, F_A1T), (OFFX_A0T, F_A0T)):
         hi, lo = f16_split(F)
         sec = blob[off:off + F.size].view(np.float16).reshape(F.shape[0], F.shape[1], 2, 64, 8)

@@ -18,14 +18,3 @@ def pytest_configure(config):
 def pkg():
     """The product package (directory name is not a python identifier)."""
     return importlib.import_module("one-2-3-45_amd")
-
-
-def pytest_collection_modifyitems(config, items):
-    """O2345_PRECISION=bf16 is the SDF throughput mode with its own stated tolerance (test_sdf_mlp_bf16); the parity tests below
-    are written for the fp32-class modes (f16x3 default, fp32), so under a global bf16 setting only the bf16 tests run on the GPU."""
-    if os.environ.get("O2345_PRECISION") != "bf16":
-        return
-    skip = pytest.mark.skip(reason="global bf16 mode: tolerance-tested by the *_bf16 tests only")
-    for it in items:
-        if "gpu" in it.keywords and "bf16" not in it.name:
-            it.add_marker(skip)

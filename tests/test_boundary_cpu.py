@@ -108,11 +108,10 @@ def test_synthetic_scene_contract():
 
 
 def test_precision_config(pkg, monkeypatch):
-    """config.py: the numerical mode of the network kernels (default f16x3; fp32 strict; bf16 = SDF throughput mode only)."""
+    """config.py: the numerical mode of the network kernels (default f16x3; fp32 strict)."""
     import importlib
     cfg = importlib.import_module("one-2-3-45_amd.config")
     assert cfg.PRECISION in cfg.PRECISIONS
-    assert cfg.sdf_precision("bf16") == "bf16" and cfg.color_precision("bf16") == "f16x3"
     assert cfg.sdf_precision("fp32") == "fp32" and cfg.color_precision("fp32") == "fp32"
     assert cfg.color_precision(None) in ("f16x3", "fp32")
     with __import__("pytest").raises(ValueError):

@@ -41,40 +41,6 @@ def test_blob_emulation_matches_oracle(pkg):
     assert np.abs(glat - glat_ref.numpy()).max() < 2e-4 * max(1.0, glat_ref.abs().max().item())
 
 
-def test_bf16_blob_emulation(pkg):
-    """csrc/sdf_mlp_bf16.hip dataflow (v_mfma_f32_32x32x16_bf16 lane layout) vs the same network evaluated in fp64 with the
-    SAME operand roundings (pins the packing to ~1e-6), and vs the unrounded oracle at the mode's stated tolerance."""
-    Wn = pkg.weights
-    W = _weights(pkg)
-    blob = Wn.pack_sdf_blob(W)
-    rng = np.random.default_rng(4)
-    pts = rng.uniform(-1, 1, (31, 3)).astype(np.float32)
-    lat = rng.normal(0, 1, (31, 16)).astype(np.float32)
-    sdf, gpe, glat = EMU.emulate_sdf_blob_bf16(blob, pts, lat)
-    q = lambda x: Wn.bf16_to_f32(Wn.bf16_round(np.asarray(x, np.float32))).astype(np.float64)
-    sp = lambda a: np.where(a * 100 > 20, a, np.log1p(np.exp(np.minimum(a * 100, 50))) / 100)
-    dsp = lambda a: 1 / (1 + np.exp(-np.clip(a * 100, -700, 700)))
-    pe = O.embed(torch.from_numpy(pts)).numpy().astype(np.float64)
-    w0, w1, w2 = (W[k].astype(np.float64) for k in ("w0", "w1", "w2"))
-    a0 = pe @ w0.T + W["b0"]
-    h0 = sp(a0)
-    a1 = np.concatenate([q(h0), q(lat)], 1) @ q(w1).T + W["b1"]
-    h1 = sp(a1)
-    ref = np.concatenate([h1, lat], 1) @ w2[0] + W["b2"][0]
-    assert np.abs(sdf - ref).max() < 2e-6
-    g1 = w2[0, :128] * dsp(a1)
-    gcat = q(g1) @ q(w1)                                   # [P,144]
-    g0 = gcat[:, :128] * dsp(a0)
-    gpe_ref = q(g0) @ q(w0)
-    glat_ref = gcat[:, 128:] + w2[0, 128:]
-    assert np.abs(gpe - gpe_ref).max() < 1e-5 * max(1.0, np.abs(gpe_ref).max())
-    assert np.abs(glat - glat_ref).max() < 1e-5 * max(1.0, np.abs(glat_ref).max())
-    # and against the exact network: bf16 operand rounding is 2^-9 relative per term
-    Wt = {k: torch.from_numpy(v) for k, v in W.items()}
-    exact = O.sdf_mlp(torch.from_numpy(pts), torch.from_numpy(lat), Wt).numpy()[:, 0]
-    assert np.abs(sdf - exact).max() < 2e-2 * max(1.0, np.abs(exact).max())
-
-
 def test_x3_blob_emulation(pkg):
     """csrc/sdf_mlp_x3.hip (split-f16 operands, three MFMAs per product) reproduces the fp32 network to fp32-class accuracy."""
     Wn = pkg.weights

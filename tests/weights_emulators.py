@@ -9,94 +9,6 @@ _w = importlib.import_module("one-2-3-45_amd.weights")
 globals().update({k: getattr(_w, k) for k in dir(_w) if not k.startswith("__")})
 
 
-def emulate_sdf_blob_bf16(blob, pts, lat):
-    """Numpy emulation of csrc/sdf_mlp_bf16.hip (one wave, 32 points): layer 0 in fp32, bf16-rounded operands for layer 1
-    and both backward GEMMs, v_mfma_f32_32x32x16_bf16 lane layout.  Returns (sdf[P], dsdf/dpe[P,39], dsdf/dlat[P,16])."""
-    pts = np.asarray(pts, np.float64)
-    P = pts.shape[0]
-    assert P <= 32
-    lane = np.arange(64)
-    j, h = lane & 31, lane >> 5
-    live = j < P
-    jj = np.minimum(j, P - 1)
-    q = lambda x: bf16_to_f32(bf16_round(np.asarray(x, np.float32))).astype(np.float64)
-
-    def out_regs(D, c):
-        out = c.copy()
-        for r in range(16):
-            out[:, r] += D[(r & 3) + 8 * (r >> 2) + 4 * h, j]
-        return out
-
-    def mfma2(a, b, c):
-        A = np.zeros((32, 2)); B = np.zeros((2, 32))
-        A[j, h] = a; B[h, j] = b
-        return out_regs(A @ B, c)
-
-    def mfma16(a8, b8, c):                      # a8/b8: [64 lanes][8]; lane supplies k = 8*(lane>>5) + t
-        A = np.zeros((32, 16)); B = np.zeros((16, 32))
-        for t in range(8):
-            A[j, 8 * h + t] = a8[:, t]; B[8 * h + t, j] = b8[:, t]
-        return out_regs(A @ B, c)
-
-    def softplus(a):
-        t = a * 100
-        z = np.exp(np.minimum(t, 50))
-        return np.where(t > 20, a, np.log1p(z) / 100), np.where(t > 20, 1.0, z / (z + 1))
-
-    misc = blob[OFF_MISC:OFF_MISC + MISC_SIZE].astype(np.float64)
-    bias = lambda off: [np.stack([misc[off + (nb * 16 + r) * 2 + h] for r in range(16)], 1) for nb in range(4)]
-    pe = np.zeros((64, 20))
-    for t in range(9):
-        c = 9 * h + t
-        f = 2.0 ** (c // 3)
-        x = pts[jj, t % 3]
-        pe[:, t], pe[:, 9 + t] = np.sin(x * f), np.cos(x * f)
-    pe[:, 18] = np.where(h == 1, pts[jj, 2], pts[jj, 0])
-    pe[:, 19] = np.where(h == 1, 0.0, pts[jj, 1])
-    latl = np.stack([lat[jj, 8 * h + t] for t in range(8)], 1)
-    A0 = blob[OFF_A0:OFF_A1].reshape(4, ST0, 64).astype(np.float64)
-    a0 = bias(MISC_B0)
-    for st in range(ST0):
-        for nb in range(4):
-            a0[nb] = mfma2(A0[nb, st], pe[:, st], a0[nb])
-    h0, s0 = zip(*[softplus(a) for a in a0])
-    halves = blob[OFFH_A1:SDF_BF16_END].view(np.uint16)
-    A1H = bf16_to_f32(halves[:4 * STH1 * 64 * 8]).reshape(4, STH1, 64, 8).astype(np.float64)
-    A1TH = bf16_to_f32(halves[(OFFH_A1T - OFFH_A1) * 2:(OFFH_A0T - OFFH_A1) * 2]).reshape(5, STHB, 64, 8).astype(np.float64)
-    A0TH = bf16_to_f32(halves[(OFFH_A0T - OFFH_A1) * 2:]).reshape(2, STHB, 64, 8).astype(np.float64)
-    kstep = lambda regs, st: q(regs[st >> 1][:, 8 * (st & 1):8 * (st & 1) + 8])
-    a1 = bias(MISC_B1)
-    for st in range(STH1):
-        b8 = kstep(h0, st) if st < 8 else q(latl)
-        for nb in range(4):
-            a1[nb] = mfma16(A1H[nb, st], b8, a1[nb])
-    h1, s1 = zip(*[softplus(a) for a in a1])
-    w2h = [np.stack([misc[MISC_W2H + (nb * 16 + r) * 2 + h] for r in range(16)], 1) for nb in range(4)]
-    part = sum((w2h[nb] * h1[nb]).sum(1) for nb in range(4)) + sum(misc[MISC_W2L + 8 * h + t] * latl[:, t] for t in range(8))
-    sdf = np.zeros(P)
-    for l in lane[live & (h == 0)]:
-        sdf[j[l]] = part[l] + part[l + 32] + misc[MISC_B2]
-    g1 = [w2h[nb] * s1[nb] for nb in range(4)]
-    g = [np.zeros((64, 16)) for _ in range(5)]
-    for st in range(STHB):
-        for nb in range(5):
-            g[nb] = mfma16(A1TH[nb, st], kstep(g1, st), g[nb])
-    g0 = [g[nb] * s0[nb] for nb in range(4)]
-    gp = [np.zeros((64, 16)) for _ in range(2)]
-    for st in range(STHB):
-        for nb in range(2):
-            gp[nb] = mfma16(A0TH[nb, st], kstep(g0, st), gp[nb])
-    gpe = np.zeros((P, 39)); glat = np.zeros((P, 16))
-    for l in lane[live]:
-        for t in range(20):
-            col = pe_index(t, int(h[l]))
-            if col >= 0:
-                gpe[j[l], col] = gp[0][l, t] if t < 16 else gp[1][l, t - 16]
-        for t in range(8):
-            glat[j[l], 8 * h[l] + t] = g[4][l, t] + misc[MISC_W2L + 8 * h[l] + t]
-    return sdf, gpe, glat
-
-
 def emulate_sdf_blob(blob, pts, lat, grad_lat_jac=None):
     """Numpy emulation of csrc/sdf_mlp.hip's dataflow (one wave, 32 points) using the documented lane layouts of
     v_mfma_f32_32x32x2_f32.  Used by the CPU tests to pin the packing; returns (y[128] per point, dsdf/dpe, dsdf/dlat)."""

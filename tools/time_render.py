@@ -33,38 +33,3 @@ print("sdf fwd  indexed", timed(lambda: ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], 
 print("color VALU indexed", timed(lambda: ops.color_points(wt.color_blob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], inp["proj"], inp["cam_pos"], pts, query_cam=inp["qcam"], index=idx, want_nviews=False)))
 print("color MFMA indexed", timed(lambda: ops.color_points(wt.color_mblob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], inp["proj"], inp["cam_pos"], pts, query_cam=inp["qcam"], index=idx, want_nviews=False, mfma=True)))
 print("view_count", timed(lambda: ops.view_count(pts, vol["maskvol"], D, inp["proj"], 8, 256, 256)))
-# bf16 throughput mode of the SDF network
-print("sdf grad bf16   ", timed(lambda: ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=2, index=idx, out=o2, precision="bf16")))
-print("sdf fwd  bf16   ", timed(lambda: ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=0, index=idx, out={"sdf": o2["sdf"]}, precision="bf16")))
-wt.sdf_precision = "bf16"
-print("render bf16 sdf", timed(full))
-ob = full()
-wt.sdf_precision = "fp32"
-for k in ("color", "depth", "weights_sum"):
-    d = (ob[k].float() - out[k].float()).abs()
-    print(f"  bf16 vs fp32 {k}: max {float(d.max()):.3e} mean {float(d.mean()):.3e}")
-print("sdf fwd  f16x3  ", timed(lambda: ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=0, index=idx, out={"sdf": o2["sdf"]}, precision="f16x3")))
-wt.sdf_precision = "f16x3"
-print("render f16x3 fwd", timed(full))
-ox = full()
-wt.sdf_precision = "fp32"
-for k in ("color", "depth", "weights_sum"):
-    d = (ox[k].float() - out[k].float()).abs()
-    print(f"  f16x3 vs fp32 {k}: max {float(d.max()):.3e} mean {float(d.mean()):.3e}")
-print("sdf grad f16x3  ", timed(lambda: ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=2, index=idx, out=o2, precision="f16x3")))
-print("color x3 indexed  ", timed(lambda: ops.color_points(wt.color_xblob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], inp["proj"], inp["cam_pos"], pts, query_cam=inp["qcam"], index=idx, want_nviews=False, mfma="x3")))
-wt.sdf_precision = "f16x3"; wt.color_precision = "f16x3"
-print("render f16x3 fwd + colour", timed(full))
-ox = full()
-wt.sdf_precision = "fp32"; wt.color_precision = "fp32"
-for k in ("color", "depth", "weights_sum"):
-    d = (ox[k].float() - out[k].float()).abs()
-    print(f"  x3 vs fp32 {k}: max {float(d.max()):.3e} mean {float(d.mean()):.3e}")
-# A/B of the tile schedule on this box: XCD-contiguous (default) vs flat block-interleaved
-import os
-for flat in ("0", "1", "0", "1"):
-    os.environ["O2345_FLAT_SCHED"] = flat
-    print("flat" if flat == "1" else "xcd ", "colour x3", timed(lambda: ops.color_points(wt.color_xblob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], inp["proj"], inp["cam_pos"], pts, query_cam=inp["qcam"], index=idx, want_nviews=False, mfma="x3"))[0],
-          "grad x3", timed(lambda: ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=2, index=idx, out=o2, precision="f16x3"))[0],
-          "fwd x3", timed(lambda: ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=0, index=idx, out={"sdf": o2["sdf"]}, precision="f16x3"))[0])
-os.environ["O2345_FLAT_SCHED"] = "0"
