@@ -115,6 +115,56 @@ def step(wt, inp, D, R_mesh, tm, chunk, imgs=None):
     return vol, outs, mesh
 
 
+def pipelined_block(dev, a, inp, imgs_list, n_streams):
+    """The SAME scenes once more, dealt round-robin to ``n_streams`` host threads, each with its own HIP stream and its own weights object (scratch and packed-weight
+    caches are per object): the latency-bound phases of one scene (volume build: ~45 short kernels and two size read-backs; marching cubes) overlap the long
+    render kernels of another.  Reported next to the contract's one-stream number, never instead of it; results are checked bit-identical to the sequential pass
+    (they were not before the library was built without packed-FP32 instructions -- profiles/NOTES.md, "co-resident MFMA")."""
+    import threading
+    K = len(imgs_list)
+    wts = [pipeline.SceneWeights(dev, seed=0, sdf_precision=a.precision, color_precision=a.precision) for _ in range(n_streams)]
+    for w in wts:
+        w.grid_tables(a.mesh_res)
+
+    def digest(vol, outs, mesh):
+        return torch.stack([outs[0]["color"].double().sum(), outs[0]["depth"].double().sum(), outs[0]["weights_sum"].double().sum(),
+                            vol["rows"].double().sum(), vol["vol_cl"].double().sum(), mesh[0].double().sum(), mesh[2].double().sum()])
+
+    def run(n):
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        dig, errs = [None] * K, []
+
+        def worker(i):
+            try:
+                torch.cuda.set_device(dev)
+                tm = Timer()
+                with torch.cuda.stream(streams[i]):
+                    for k in range(i, K, n):
+                        out = step(wts[i], inp, a.vol, a.mesh_res, tm, a.ray_chunk, imgs=imgs_list[k])
+                        dig[k] = digest(*out)
+                        out = None
+                    streams[i].synchronize()
+            except Exception as e:                                   # noqa: BLE001
+                errs.append(e)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(n)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if errs:
+            raise errs[0]
+        return dt / K * 1e3, torch.stack(dig).cpu()
+    run(n_streams)                                                   # every stream's memory pools filled before anything is timed
+    ms1, d1 = run(1)
+    msn, dn = run(n_streams)
+    n_rays = inp["rays_o"].shape[0]
+    return {"streams": n_streams, "scenes": K, "ms_per_scene": msn, "rays_per_s": n_rays / (msn * 1e-3), "ms_per_scene_one_thread_same_harness": ms1,
+            "bit_identical_to_sequential": bool(torch.equal(d1, dn)),
+            "note": "throughput of K scenes in flight on several streams of ONE GPU; the contract's value / ms_per_step above is the one-stream number"}
+
+
 def render_order_index(pm):
     """Slots (s * R + r) of the occupied mid-points in the order k_ray_finalize writes its list: wave-major (64 consecutive rays),
     sample-major inside a wave.  pm [S, R]."""
@@ -406,6 +456,7 @@ def main():
                                                              "--backend gloo, RCCL refuses duplicate devices).  The number it prints is not a scaling measurement")
     ap.add_argument("--precision", choices=config.PRECISIONS, default=config.PRECISION,
                     help="network kernels: f16x3 (default; split-f16 MFMA, fp32-class accuracy), fp32 (exact fp32 MFMA)")
+    ap.add_argument("--streams", type=int, default=2, help="extra block \"pipelined\": the timed scenes once more on this many streams (0/1 = skip); N = 1 only")
     ap.add_argument("--ckpt", default=None, help="checkpoint in the reference's format (exp_runner...:514-541); default: seeded stand-in weights, identical on every rank")
     ap.add_argument("--broadcast-weights", action="store_true", help="with --ckpt: rank 0 reads the file, ONE RCCL broadcast hands the weights to the other ranks "
                                                                       "(the north star's optional shared-backbone broadcast); default: every rank reads the file")
@@ -483,7 +534,11 @@ def main():
         print({k: st[k] for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "reserved_bytes.all.peak", "allocated_bytes.all.peak")}, file=sys.stderr)
     n_rays = inp["rays_o"].shape[0]
     ms_step = dt / a.steps * 1e3
-    c3 = None
+    c3 = piped = None
+    if not a.quick and world == 1 and a.streams > 1 and not a.same_scene and not a.ckpt:
+        vol_keep = (vol, outs, mesh)
+        piped = pipelined_block(dev, a, inp, scene_imgs[a.warmup:], a.streams)
+        vol, outs, mesh = vol_keep
     if not a.quick:
         scene_imgs = None
         c3 = c3_block(dev, wt, inp, a, rank, world)          # all ranks take part (barrier + max-over-ranks clock inside)
@@ -526,6 +581,8 @@ def main():
         }
         if c3 is not None:
             result["c3"] = c3
+        if piped is not None:
+            result["pipelined"] = piped
         if a.precision != "fp32":
             # the same three kernels in the exact fp32 MFMA form, priced against the fp32 matrix peak (strict mode of the library)
             kf = kernel_times(wt, vol, inp, outs, a.vol, reps=3, sdf_precision="fp32", color_precision="fp32")
