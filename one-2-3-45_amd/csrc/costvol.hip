@@ -101,7 +101,11 @@ __device__ __forceinline__ void tap4_accumulate(const float4* __restrict__ base,
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (w[k] != 0.f) {              // fully-outside taps: no load (zero padding)
+#ifdef O2345_COSTVOL_TAPMASK      // timing experiment only (wrong results): every tap falls into a few L1-resident lines -> what is left is issue + VALU
+            const float4 a = base[(size_t)(idx[k] & O2345_COSTVOL_TAPMASK) * 4];
+#else
             const float4 a = base[(size_t)idx[k] * 4];
+#endif
             f.x += a.x * w[k]; f.y += a.y * w[k]; f.z += a.z * w[k]; f.w += a.w * w[k];
         }
     }
