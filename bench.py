@@ -198,6 +198,9 @@ def kernel_times(wt, vol, inp, outs, D, reps=5, sdf_precision=None, color_precis
     R = o["pm"].shape[1]
     idx = render_order_index(o["pm"])
     pts = (inp["rays_o"][None, :R] + inp["rays_d"][None, :R] * o["mid_z"][..., None]).reshape(-1, 3).contiguous()
+    if os.environ.get("O2345_LIST_SORT", "1") != "0":           # what o2345_render_rays does to its list before the network kernels (csrc/list_sort.hip)
+        res["list_sort_ms"] = timed(lambda: ops.list_sort_by_visibility(pts, idx, inp["proj"], 256, 256))
+        idx = ops.list_sort_by_visibility(pts, idx, inp["proj"], 256, 256)
     res["n_valid_points"] = int(idx.numel())
     res["n_points"] = int(pts.shape[0])
     o2 = {"sdf": torch.empty(pts.shape[0], device=dev), "grad": torch.empty(pts.shape[0], 3, device=dev)}

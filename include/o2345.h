@@ -202,6 +202,13 @@ typedef struct O2345RenderIO {
     const float* color_x3_blob;     /* optional: split-f16 colour kernels (take precedence over color_mfma_blob) */
     const float* t_rand;            /* optional [R][n_samples]: the reference's perturb > 0 jitter, drawn by the caller (ABI 1.2) */
 } O2345RenderIO;
+/* The occupied-point list of a render call grouped, stably, by view-visibility signature (bit v = the point projects inside view v): every 32-point tile of the
+ * colour kernels then holds points that see the same views, and the kernels skip the views nobody sees.  The network kernels scatter by slot, so their
+ * results do not depend on the order (no reference counterpart: the reference evaluates every (point, view) pair, models/projector.py:96-228).
+ * list [<= n_max] slots, *count_dev entries (device-side count); list_out != list; keys_out (optional) receives the signatures in output order. */
+size_t o2345_list_sort_workspace_bytes(long long n_max, int V);
+int o2345_list_sort_by_visibility(const float* pts, const int32_t* list, const int32_t* count_dev, long long n_max, const float* proj, int V, int H, int W,
+                                  int32_t* list_out, uint32_t* keys_out, void* workspace, size_t workspace_bytes, void* stream);
 size_t o2345_render_workspace_bytes(int R, int n_samples, int n_importance);
 int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libo2345_hip.so")
-SOURCES = ["api.cpp", "costvol.hip", "sparse.hip", "sparse_mfma.hip", "sdf_mlp.hip", "sdf_mlp_x3.hip", "render.hip", "color.hip", "color_mfma.hip", "color_pts.hip", "mcubes.hip", "mesh_pack.hip", "featmaps.hip", "convnet.hip"]
+SOURCES = ["api.cpp", "costvol.hip", "sparse.hip", "sparse_mfma.hip", "sdf_mlp.hip", "sdf_mlp_x3.hip", "render.hip", "list_sort.hip", "color.hip", "color_mfma.hip", "color_pts.hip", "mcubes.hip", "mesh_pack.hip", "featmaps.hip", "convnet.hip"]
 # No packed-FP32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  Measured on MI355X (profiles/NOTES.md, "co-resident MFMA"): the cost-volume
 # gather built WITH them returns garbage in lanes 48..63 of some waves whenever a kernel of ANOTHER stream that issues MFMA shares its SIMDs (23 of 400 launches next
 # to a pure-MFMA loop, 77 of 80 next to the brick sparse convolution); built without them: 0 of 400, same speed, and whole scenes on 2-4 streams become bit-identical

@@ -15,5 +15,5 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 const char* o2345_last_error(void) { return o2345::g_err; }
-int o2345_version(void) { return 130; }     // 1.2: O2345RenderIO.t_rand + o2345_ray_coarse_jitter (perturb > 0); 1.3: o2345_conv2d family
+int o2345_version(void) { return 150; }     // 1.5: o2345_list_sort_by_visibility (render work-list grouped by visibility); 1.4: color stats, bf16 entry removed; 1.2: O2345RenderIO.t_rand + o2345_ray_coarse_jitter (perturb > 0); 1.3: o2345_conv2d family
 }

@@ -236,9 +236,17 @@ int o2345_ray_composite(const float* rays_o, const float* rays_d, int R, int S, 
 // ---- the whole render() call -----------------------------------------------------------------------------------------
 // Workspace layout (floats unless noted), S = n_samples + n_importance, R rays:
 //   z[S*R] sdf[S*R] wbuf[S*R] new_z[NI*R] new_sdf[NI*R] pts[3*S*R] list[S*R ints] count[16 ints]
-size_t o2345_render_workspace_bytes(int R, int n_samples, int n_importance) {
+//   ... sorted list[S*R ints] + the workspace of o2345_list_sort_by_visibility for up to 32 views (csrc/list_sort.hip)
+size_t o2345_list_sort_workspace_bytes(long long n_max, int V);
+int o2345_list_sort_by_visibility(const float* pts, const int32_t* list, const int32_t* count_dev, long long n_max, const float* proj, int V, int H, int W,
+                                  int32_t* list_out, uint32_t* keys_out, void* workspace, size_t workspace_bytes, void* stream);
+static size_t render_core_workspace_bytes(int R, int n_samples, int n_importance) {
     const size_t S = (size_t)n_samples + n_importance, NI = (size_t)(n_importance / 4 > 0 ? n_importance / 4 : 1);
     return ((S * 3 + NI * 2 + 3 * S + S) * (size_t)R + 64) * 4;
+}
+size_t o2345_render_workspace_bytes(int R, int n_samples, int n_importance) {
+    const size_t S = (size_t)n_samples + n_importance;
+    return render_core_workspace_bytes(R, n_samples, n_importance) + S * (size_t)R * 4 + o2345_list_sort_workspace_bytes((long long)(S * (size_t)R), 32);
 }
 
 struct O2345RenderIO {
@@ -296,6 +304,18 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     float* fpts = pts;   // reuse
     if ((rc = ray_finalize_launch(io->rays_o, io->rays_d, R, z, (int)S, sample_dist, io->maskvol, io->D, io->mid_z, io->dists, fpts, io->pm, io->sdf, io->grad, io->rgb, list, count, stream, 0))) return rc;
     hipLaunchKernelGGL(k_quirk_first100, dim3(1), dim3(128), 0, s, count, list, R, (int)S);
+    // the list grouped by view-visibility signature (stable): the colour kernel then skips every (tile, view) pair in which no point sees the view instead of
+    // 3/4 of them -- 40.0 -> 36.1 ms at 8 views, bit-identical results (csrc/list_sort.hip).  O2345_LIST_SORT=0: the emission order (A/B knob)
+    {
+        const char* e = getenv("O2345_LIST_SORT");
+        if (!(e && e[0] == '0') && io->V <= 32) {
+            int* slist = (int*)((char*)workspace + render_core_workspace_bytes(R, NS, NIMP));
+            void* sort_ws = (void*)(slist + S * RR);
+            if ((rc = o2345_list_sort_by_visibility(fpts, list, count, (long long)(S * RR), io->proj, io->V, io->H, io->W, slist, nullptr, sort_ws,
+                                                    o2345_list_sort_workspace_bytes((long long)(S * RR), 32), stream))) return rc;
+            list = slist;
+        }
+    }
     if ((rc = sdf_eval(2, fpts, list, count, 0, io->sdf, io->grad))) return rc;
     // valid-view counts (feed the per-ray colour mask): the colour kernels write them for the points they evaluate (the occupied ones, 88 % at
     // BASELINE config 2); this pass covers the rest (four IEEE divisions per view make it VALU-bound: 0.48 ms over all points)

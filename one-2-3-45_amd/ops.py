@@ -480,6 +480,26 @@ def view_count(pts, maskvol, D, proj, V, H, W):
     return out
 
 
+@_on_device
+def list_sort_by_visibility(pts, index, proj, H, W, count=None, want_keys=False):
+    """index [n] int32 slots into pts [P,3] -> the same entries grouped, stably, by view-visibility signature (what o2345_render_rays does to its
+    occupied-point list before the network kernels; csrc/list_sort.hip).  count (optional int32[1] on the device): number of valid entries."""
+    L = _lib.lib()
+    n = int(index.shape[0])
+    V = int(proj.shape[0])
+    out = torch.empty_like(index)
+    if n == 0:
+        return (out, torch.empty(0, dtype=torch.int32, device=index.device)) if want_keys else out
+    if count is None:
+        count = torch.tensor([n], dtype=torch.int32, device=index.device)
+    keys = torch.empty(n, dtype=torch.int32, device=index.device) if want_keys else None
+    wsb = L.o2345_list_sort_workspace_bytes(n, V)
+    ws = _workspace(wsb, index.device, "lsort")
+    check(L.o2345_list_sort_by_visibility(_p(pts), _p(index, torch.int32), _p(count, torch.int32), n, _p(proj), V, int(H), int(W), _p(out, torch.int32),
+                                          _p(keys, torch.int32), _p(ws, torch.uint8), wsb, _stream()), "list_sort_by_visibility")
+    return (out, keys) if want_keys else out
+
+
 # ---------------------------------------------------------------------------------------------------------- rays
 @_on_device
 def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64, inv_s=None, alpha_inter_ratio=1.0,

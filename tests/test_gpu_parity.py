@@ -653,3 +653,37 @@ def test_view_skipping_is_bit_identical(dev, ops, V, monkeypatch):
     rgb_ref, nv_ref = O.rendering_network(color_t(s["color_sd"]), geo, rf, rdf, vm)
     assert torch.equal(ref[1].cpu().float(), nv_ref)
     close(outs["10"][0], rgb_ref, rel=1e-4, what="blended colour with view skipping")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V", [5, 8, 19, 32])
+def test_list_sort_by_visibility(pkg, ops, V):
+    """o2345_list_sort_by_visibility: a stable permutation of the list, signatures ascending, signatures = 'projects strictly inside view v' (checked against torch on
+    the same points, borderline points aside), entries past the device-side count untouched; and the colour kernel's results do not depend on the order."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(V)
+    P_ = 300000
+    pts = (torch.rand(P_, 3, generator=g) * 2 - 1).to(dev)
+    sc = pkg.synth.make_scene(V, image_seed=1)
+    pipeline = importlib.import_module("one-2-3-45_amd.pipeline")
+    proj, _ = pipeline.camera_terms(torch.from_numpy(sc["intrinsics"]).to(dev), torch.from_numpy(sc["w2cs"]).to(dev))
+    proj = proj.float().contiguous()
+    keep = torch.rand(P_, generator=g) < 0.7
+    index = torch.nonzero(keep).flatten().to(torch.int32).to(dev)                 # ascending slots: stability is visible in the values
+    n = index.numel()
+    n_valid = n - 1234
+    count = torch.tensor([n_valid], dtype=torch.int32, device=dev)
+    out, keys = ops.list_sort_by_visibility(pts, index, proj, 256, 256, count=count, want_keys=True)
+    o, k = out[:n_valid].long(), keys[:n_valid].long() & 0xFFFFFFFF
+    assert torch.equal(torch.sort(o)[0], index[:n_valid].long()), "not a permutation of the valid entries"
+    assert bool((k[1:] >= k[:-1]).all()), "signatures not ascending"
+    same = k[1:] == k[:-1]
+    assert bool((o[1:][same] > o[:-1][same]).all()), "not stable inside a signature"
+    p = pts[o]
+    ref = torch.zeros_like(k)
+    for v in range(V):
+        pr = p @ proj[v, :, :3].T + proj[v, :, 3]
+        z = pr[:, 2].clamp(min=1e-3)
+        ref |= ((pr[:, 0] > 0) & (pr[:, 0] < 255 * z) & (pr[:, 1] > 0) & (pr[:, 1] < 255 * z)).long() << v
+    assert float((ref != k).float().mean()) < 1e-3
+    assert int(torch.unique(k).numel()) > 3
