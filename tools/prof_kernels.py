@@ -15,6 +15,8 @@ out = pipeline.render(wt, vol, inp["proj"], inp["cam_pos"], inp["rays_o"], inp["
 pm = out["pm"].reshape(-1)
 idx = bench.render_order_index(out["pm"])
 pts = (inp["rays_o"][None] + inp["rays_d"][None] * out["mid_z"][..., None]).reshape(-1, 3).contiguous()
+if os.environ.get("O2345_LIST_SORT", "1") != "0":
+    idx = ops.list_sort_by_visibility(pts, idx, inp["proj"], 256, 256)        # the order o2345_render_rays hands to the network kernels (csrc/list_sort.hip)
 o2 = {"sdf": torch.empty(pts.shape[0], device=dev), "grad": torch.empty(pts.shape[0], 3, device=dev)}
 V = inp["imgs"].shape[0]
 import os
