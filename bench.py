@@ -571,6 +571,7 @@ def main():
             "volume_build_ms": tm.mean("volume"), "render_ms": tm.mean("render"),
             "mesh": {"vertices": int(mesh[0].shape[0]), "triangles": int(mesh[1].shape[0])}, "kept_voxels": n_vox,
             "occupied_points": nvp, "sampled_points": npts,
+            "list_sort_ms": kt.get("list_sort_ms"),      # csrc/list_sort.hip: the occupied-point list grouped by view-visibility signature (inside every render call)
             # dominant kernel of a step = the colour network: ALGORITHMIC FLOP (38,544 per (point, view)) x occupied
             # points x views / HIP-event time of that launch, against the dense MFMA peak of the type the matrix pipe runs in
             "roofline": dict(rl["color"], traffic=pmc_traffic(COLOR_KERNEL_PREFIX),
