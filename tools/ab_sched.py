@@ -37,16 +37,5 @@ for V, D, scale in ((8, 128, 2), (32, 96, 1)):
     res[f"V{V}_nviews_equal"] = bool(torch.equal(base["pts"][1], base["tiles"][1]))
     nvl = base["pts"][1][idx.long()].float()
     res[f"V{V}_points"] = int(idx.numel()); res[f"V{V}_mean_visible_views"] = float(nvl.mean()); res[f"V{V}_points_without_view"] = int((nvl == 0).sum())
-    # how coherent visibility is: fraction of (tile of 32 list entries, view) pairs with at least one visible point, from a host-side recount
-    if V == 8:
-        P = inp["proj"]
-        p = pts[idx.long()]
-        ph = torch.cat([p, torch.ones_like(p[:, :1])], 1)
-        pr = torch.einsum("vij,nj->vni", P, ph)
-        z = pr[..., 2].clamp(min=1e-3)
-        m = ((2 * (pr[..., 0] / z) / 255 - 1).abs() < 1) & ((2 * (pr[..., 1] / z) / 255 - 1).abs() < 1)
-        nt = m.shape[1] // 32
-        res["V8_tile_view_pairs_with_work"] = float(m[:, :nt * 32].reshape(V, nt, 32).any(2).float().mean())
-        res["V8_point_view_pairs_visible"] = float(m.float().mean())
-    del vol, out, pts
+    # (tile-level / point-level visibility statistics: tools/ab_sorted_list.py and the kernel's own work counters, ops.color_stats)
 print(json.dumps(res))
