@@ -198,7 +198,7 @@ def kernel_times(wt, vol, inp, outs, D, reps=5, sdf_precision=None, color_precis
     R = o["pm"].shape[1]
     idx = render_order_index(o["pm"])
     pts = (inp["rays_o"][None, :R] + inp["rays_d"][None, :R] * o["mid_z"][..., None]).reshape(-1, 3).contiguous()
-    if os.environ.get("O2345_LIST_SORT", "1") != "0":           # what o2345_render_rays does to its list before the network kernels (csrc/list_sort.hip)
+    if b"list_sort=1" in ops._lib.lib().o2345_knobs():           # what o2345_render_rays does to its list before the network kernels (csrc/list_sort.hip)
         res["list_sort_ms"] = timed(lambda: ops.list_sort_by_visibility(pts, idx, inp["proj"], 256, 256))
         idx = ops.list_sort_by_visibility(pts, idx, inp["proj"], 256, 256)
     res["n_valid_points"] = int(idx.numel())
@@ -211,11 +211,11 @@ def kernel_times(wt, vol, inp, outs, D, reps=5, sdf_precision=None, color_precis
         blob, mode = wt.color_xblob, "x3"
     else:
         blob, mode = wt.color_mblob, True
-    color = lambda: ops.color_points(blob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], inp["proj"], inp["cam_pos"], pts,
-                                     query_cam=inp["qcam"], index=idx, want_nviews=False, mfma=mode)
+    color = lambda stats=None: ops.color_points(blob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], inp["proj"], inp["cam_pos"], pts,
+                                                query_cam=inp["qcam"], index=idx, want_nviews=False, mfma=mode, stats=stats)
     res["color_ms"] = timed(color)
-    # how much of the (tile, view) grid the kernel evaluated (views that see none of a tile's 32 points are skipped): device-side counters
-    ops.color_stats(True); color(); res["color_work"] = ops.color_stats_read(); ops.color_stats(False)
+    # how much of the (tile, view) grid the kernel evaluated (views that see none of a tile's 32 points are skipped): caller-owned device counters
+    st = ops.color_stats_buffer(dev); color(st); res["color_work"] = ops.color_stats_read(st)
     return res
 
 

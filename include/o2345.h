@@ -25,7 +25,19 @@ extern "C" {
 #endif
 
 const char* o2345_last_error(void);
+/* 200 = ABI 2.0 (round 4): O2345RenderIO re-laid out (sdf_mode replaces the fossil name sdf_bf16; color_blob / the VALU colour kernel removed;
+ * per-ray near / far; caller-owned colour work counters; per-call scalars) and layout-checked (o2345_render_io_*), o2345_camera_terms,
+ * `identity_rows` on o2345_sparse_conv3d_x3, no process-global state left in the library (the colour work counters are a caller-owned buffer). */
 int o2345_version(void);
+/* Layout self-description of O2345RenderIO as THIS library was compiled (sizeof, and offsetof of every field in declaration order): a binding
+ * asserts its own struct against it at load time (one-2-3-45_amd/_lib.py does) -- a field added on one side only cannot corrupt calls silently.
+ * render_io_layout writes min(n, number of fields) offsets and returns the number of fields. */
+size_t o2345_render_io_size(void);
+int o2345_render_io_layout(size_t* offsets_host, int n);
+/* The debug / A-B knobs this library instance runs with, e.g. "list_sort=1 sparse_brick=1 flat_sched=0 color_tiles=0 color_sched=10".  They are read from
+ * the environment (O2345_LIST_SORT, O2345_SPARSE_BRICK, O2345_FLAT_SCHED, O2345_COLOR_KERNEL, O2345_COLOR_SCHED) ONCE, at the first call that needs
+ * them -- this call included --, never on a launch path. */
+const char* o2345_knobs(void);
 
 /* ---- cost volume -------------------------------------------------------------------------------------------------
  * replaces: ops/generate_grids.py:4 generate_grid, ops/back_project.py:5 back_project_sparse_type (both calls),
@@ -112,10 +124,15 @@ int o2345_sparse_conv3d(int mode, const float* in, int cin, const int32_t* in_gr
                         const int32_t* out_coords, int n_out, int ts_out, const float* kernel, int cout, float* out,
                         void* stream);
 /* the same convolution on the f16 matrix cores in split precision (fp32-class accuracy, see o2345_sdf_mlp_x3);
- * wblob: the kernel packed by weights.pack_sparse_conv_x3, o2345_sparse_conv_x3_blob_floats(cin, cout) floats */
+ * wblob: the kernel packed by weights.pack_sparse_conv_x3, o2345_sparse_conv_x3_blob_floats(cin, cout) floats.
+ * identity_rows != 0 (mode 0 only): the CALLER GUARANTEES that out_coords is the coordinate list in_grid was built from, in the same order
+ * (output row q = input row q, n_out = number of input rows) -- what a stride-1 spnn.Conv3d always produces.  Only then may the LDS-tiled brick
+ * kernel run (32 -> 16 channels: it writes out[in_grid[site]] and never reads out_coords); with identity_rows = 0 every shape takes the gather
+ * form, which honours any subset / order of out_coords. */
 int o2345_sparse_conv_x3_blob_floats(int cin, int cout);
 int o2345_sparse_conv3d_x3(int mode, const float* in, int cin, const int32_t* in_grid, int gx, int gy, int gz,
-                           const int32_t* out_coords, int n_out, int ts_out, const float* wblob, int cout, float* out, void* stream);
+                           const int32_t* out_coords, int n_out, int ts_out, const float* wblob, int cout, int identity_rows, float* out,
+                           void* stream);
 size_t o2345_bn_workspace_bytes(int C);
 /* spnn.BatchNorm in training mode (batch statistics; the reference never calls .eval()) + activation (+ skip):
  * y = act(bn(x)) [+ skip]; slope 0 = ReLU.  mean_var_out [2,C] optional. */
@@ -169,8 +186,14 @@ int o2345_ray_coarse(const float* rays_o, const float* rays_d, int R, float near
  * torch.rand(z_vals.shape) returns) or NULL */
 int o2345_ray_coarse_jitter(const float* rays_o, const float* rays_d, int R, float near, float far, int S,
                             const float* t_rand, float* z, float* pts, void* stream);
+/* the same with per-ray near / far [R] (the reference broadcasts near + (far - near) * linspace per ray, :486-490) */
+int o2345_ray_coarse_per_ray(const float* rays_o, const float* rays_d, int R, const float* near_ray, const float* far_ray, int S,
+                             const float* t_rand, float* z, float* pts, void* stream);
+/* up_sample + sample_pdf of one round (:73-115, render_utils.py:8-51): z / sdf [S][R] sorted per ray -> new_z [n_imp][R], their points, new_sdf = 100
+ * (the cat_z_vals default), and the list of new points inside the mask (slots t * R + r) with its device-side count.  (ABI 1.x took a scratch
+ * array `wbuf`: the section weights live in LDS now.) */
 int o2345_ray_upsample(const float* rays_o, const float* rays_d, int R, const float* z, const float* sdf, int S,
-                       float inv_s, const float* maskvol, int D, float* wbuf, int n_imp, float* new_z, float* new_pts,
+                       float inv_s, const float* maskvol, int D, int n_imp, float* new_z, float* new_pts,
                        float* new_sdf, int32_t* list, int32_t* count_dev, void* stream);
 int o2345_ray_merge(int R, float* z, float* sdf, int S, float* new_z, float* new_sdf, int n_new, void* stream);
 /* finalize: mid points, section lengths, occupancy of the mid points and the list of occupied slots; every slot of sdf / grad / rgb receives the
@@ -185,22 +208,40 @@ int o2345_ray_composite(const float* rays_o, const float* rays_d, int R, int S, 
                         float* weights, float* cdf, float* weights_sum, float* weights_max, float* depth_var,
                         float* alpha_sum, float* grad_err, uint8_t* color_mask, void* stream);
 
+/* One render() call (models/sparse_neus_renderer.py:457-635).  The struct is declared HERE only: csrc/ includes this header, the ctypes binding
+ * generates its Structure from this text and checks it against o2345_render_io_size / o2345_render_io_layout of the loaded library. */
 typedef struct O2345RenderIO {
     /* scene */
-    const float* sdf_blob; const float* color_blob; const float* vol_cl; const float* maskvol; int D;
-    const float* cmaps; const float* proj; const float* cam_pos; int V, H, W;
+    const float* sdf_blob;          /* weights.pack_sdf_blob */
+    const float* color_x3_blob;     /* split-f16 colour network (weights.pack_color_x3_blob); takes precedence */
+    const float* color_mfma_blob;   /* fp32 matrix-core colour network (weights.pack_color_mfma_blob); one of the two is required */
+    const float* vol_cl;            /* [D,D,D,16] */
+    const float* maskvol;           /* [D^3] */
+    const float* cmaps;             /* [V,H,W,64] */
+    const float* proj;              /* [V,3,4] */
+    const float* cam_pos;           /* [V,3] */
+    int D, V, H, W;
     /* rays */
-    const float* rays_o; const float* rays_d; int R; float near, far; int n_samples, n_importance;
-    float inv_s, alpha_inter_ratio, background; const float* query_cam;
-    /* outputs */
+    const float* rays_o; const float* rays_d;
+    const float* near_ray;          /* optional [R]: per-ray near / far (the reference's [N_rays,1] form, :486-490); NULL: the scalars below */
+    const float* far_ray;
+    const float* query_cam;         /* [3] */
+    const float* t_rand;            /* optional [R][n_samples]: the reference's perturb > 0 jitter, drawn by the caller */
+    int R, n_samples, n_importance;
+    int sdf_mode;                   /* 0: exact fp32 MFMA SDF kernels; 2: split-f16 ("f16x3", fp32-class accuracy).  (ABI 1.x called this sdf_bf16.) */
+    float near, far;                /* used when near_ray == NULL */
+    float sample_dist;              /* length of the last section (:484: ((far - near) / n_samples).mean()); <= 0: (far - near) / n_samples */
+    float inv_s, alpha_inter_ratio, background;
+    /* outputs: per-sample arrays are sample-major [S][R] (+[,3]) */
     float* mid_z; float* dists; float* pm; float* sdf; float* grad; float* rgb; uint8_t* nviews;
     float* color; float* depth; float* weights; float* cdf; float* weights_sum; float* weights_max; float* depth_var;
-    float* alpha_sum; float* grad_err; uint8_t* color_mask; float* z_vals;
-    const float* color_mfma_blob;   /* optional: use the fp32 matrix-core colour kernels */
-    int sdf_bf16;                   /* SDF network mode: 0 exact fp32 MFMA; 2 split-f16 ("f16x3", fp32-class
-                                     * accuracy: o2345_sdf_mlp_x3 / o2345_sdf_grad_x3) */
-    const float* color_x3_blob;     /* optional: split-f16 colour kernels (take precedence over color_mfma_blob) */
-    const float* t_rand;            /* optional [R][n_samples]: the reference's perturb > 0 jitter, drawn by the caller (ABI 1.2) */
+    float* alpha_sum; float* grad_err; uint8_t* color_mask;
+    float* z_vals;                  /* optional [S][R] */
+    float* scalars;                 /* optional [4]: alpha_sum.mean(), alpha_sum.sum() / (R S), sum grad_err[.,0] / (sum grad_err[.,1] + 1e-5), number of
+                                     * evaluated list entries (fixed-order fp64 reduction, deterministic): the scalar entries of render()'s returned
+                                     * dict (alpha_sum, alpha_mean, gradient_error_fine; :586-633) without a pass over the per-ray arrays */
+    unsigned long long* color_stats;/* optional [4] device counters the colour kernel ADDS to (diagnostics, caller-owned and caller-zeroed): (32-point tile,
+                                     * view) pairs evaluated in the pooling pass / the network pass, tiles, tiles that evaluated every view */
 } O2345RenderIO;
 /* The occupied-point list of a render call grouped, stably, by view-visibility signature (bit v = the point projects inside view v): every 32-point tile of the
  * colour kernels then holds points that see the same views, and the kernels skip the views nobody sees.  The network kernels scatter by slot, so their
@@ -209,13 +250,19 @@ typedef struct O2345RenderIO {
 size_t o2345_list_sort_workspace_bytes(long long n_max, int V);
 int o2345_list_sort_by_visibility(const float* pts, const int32_t* list, const int32_t* count_dev, long long n_max, const float* proj, int V, int H, int W,
                                   int32_t* list_out, uint32_t* keys_out, void* workspace, size_t workspace_bytes, void* stream);
-size_t o2345_render_workspace_bytes(int R, int n_samples, int n_importance);
+/* V: the scene's view count -- the list-sort buffers are part of the workspace only when the call will sort its list (V <= 32 and at least 2^20 sample slots) */
+size_t o2345_render_workspace_bytes(int R, int n_samples, int n_importance, int V);
 int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace_bytes, void* stream);
+
+/* proj [V,3,4] = intrinsics [V,3,3] @ w2cs[:, :3, :] (models/render_utils.py:106) and cam_pos [V,3] = inverse(w2cs)[:, :3, 3] (models/projector.py:60-70)
+ * in ONE launch, no BLAS / solver library behind it (the first torch.matmul + torch.inverse of a process cost 180 ms of library initialisation
+ * inside the reference's own timing bracket).  Products are fp32 FMA chains in k order (what rocBLAS / ATen evaluate for k = 3); the inverse is a
+ * general 4x4 inverse by cofactors in fp64, rounded once to fp32 (singular w2c: cam_pos = inf / nan like torch.inverse's). */
+int o2345_camera_terms(const float* intrinsics, const float* w2cs, int V, float* proj_out, float* cam_pos_out, void* stream);
 
 /* ---- colour blending (replaces models/projector.py:96 Projector.compute / :231 compute_view_independent +
  * models/rendering_network.py:75 GeneralRenderingNetwork.forward) ---------------------------------------------------
  * cmaps [V,H,W,64] = rgb(3) | features(56) | pad; proj [V,3,4] = K @ w2c[:3]; cam_pos [V,3]. */
-int o2345_color_blob_floats(void);
 int o2345_pack_color_maps(const float* feat_nchw, const float* color_nchw, int V, int H, int W, float* out_nhwc64,
                           void* stream);
 int o2345_view_count(const float* pts, long long n, const float* maskvol, int D, const float* proj, int V, int H, int W,
@@ -223,29 +270,24 @@ int o2345_view_count(const float* pts, long long n, const float* maskvol, int D,
 /* the same count only where skip_if_positive[i] <= 0 (NULL: everywhere): the colour kernels write out_nviews for the points they evaluate */
 int o2345_view_count_unlisted(const float* pts, long long n, const float* skip_if_positive, const float* maskvol, int D, const float* proj,
                               int V, int H, int W, uint8_t* out, void* stream);
-int o2345_color_points(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
-                       const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
-                       const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
-                       const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
-/* same function with every linear layer on fp32 MFMA (any V >= 1: k_color_mfma for power-of-two view counts up to 32, k_color_pts
- * otherwise -- csrc/color_mfma.hip, csrc/color_pts.hip); blob from weights.pack_color_mfma_blob */
+/* Projector + GeneralRenderingNetwork fused, every linear layer on fp32 MFMA (k_color_pts, csrc/color_pts.hip: a wave owns 32 points and walks the
+ * views; any V in [1,255]); blob from weights.pack_color_mfma_blob.  pts [P,3]; index / n_dev: optional list of point slots + device-side count;
+ * exactly one of query_cam [3] (Projector.compute) / normals [P,3] (compute_view_independent).  out_rgb [P,3], out_nviews [P] (optional).
+ * stats_dev (optional, [4], caller-owned and caller-zeroed): work counters the launch ADDS to -- (32-point tile, view) pairs evaluated in the
+ * pooling pass / the network pass, tiles, tiles that evaluated every view.  (ABI 1.x kept these in a process-global buffer; the pure-VALU
+ * kernel o2345_color_points of ABI 1.x is gone: 206 ms against 37.) */
 int o2345_color_mfma_blob_floats(void);
 int o2345_color_points_mfma(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
                             const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
                             const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
-                            const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
-/* diagnostics of the points-as-columns colour kernel (no reference counterpart): enable != 0 zeroes four device counters that every following launch
- * of this process adds to -- [0] (32-point tile, view) pairs evaluated in the pooling pass, [1] in the network pass, [2] tiles, [3] tiles that evaluated
- * every view because one of their points has no visible view; read copies them to the host (synchronises the stream) */
-int o2345_color_stats_enable(int enable, void* stream);
-int o2345_color_stats_read(unsigned long long* out4, void* stream);
+                            const float* normals, float* out_rgb, uint8_t* out_nviews, unsigned long long* stats_dev, void* stream);
 /* same kernel, split-f16 matrix steps (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulate; fp32-class
  * accuracy, see o2345_sdf_mlp_x3); blob from weights.pack_color_x3_blob */
 int o2345_color_x3_blob_floats(void);
 int o2345_color_points_x3(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
                           const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
                           const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
-                          const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
+                          const float* normals, float* out_rgb, uint8_t* out_nviews, unsigned long long* stats_dev, void* stream);
 /* GeneralRenderingNetwork.forward on MATERIALISED inputs in the reference's own (view-major) layout (models/rendering_network.py:75-129):
  * geometry_feat [P,16], rgb_feat [V,P,59] (colours | features), ray_diff [V,P,4], mask [V,P] (non-zero = valid) -> rgb [P,3] and the number of
  * valid views [P] (optional).  blob: the x3 (x3 = 1) or fp32-MFMA (x3 = 0) packing of the network.  The fused Projector path above is the fast

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libo2345_hip.so")
-SOURCES = ["api.cpp", "costvol.hip", "sparse.hip", "sparse_mfma.hip", "sdf_mlp.hip", "sdf_mlp_x3.hip", "render.hip", "list_sort.hip", "color.hip", "color_mfma.hip", "color_pts.hip", "mcubes.hip", "mesh_pack.hip", "featmaps.hip", "convnet.hip"]
+SOURCES = ["api.cpp", "costvol.hip", "sparse.hip", "sparse_mfma.hip", "sdf_mlp.hip", "sdf_mlp_x3.hip", "render.hip", "list_sort.hip", "color_maps.hip", "color_mfma.hip", "color_pts.hip", "mcubes.hip", "mesh_pack.hip", "featmaps.hip", "convnet.hip"]
 # No packed-FP32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  Measured on MI355X (profiles/NOTES.md, "co-resident MFMA"): the cost-volume
 # gather built WITH them returns garbage in lanes 48..63 of some waves whenever a kernel of ANOTHER stream that issues MFMA shares its SIMDs (23 of 400 launches next
 # to a pure-MFMA loop, 77 of 80 next to the brick sparse convolution); built without them: 0 of 400, same speed, and whole scenes on 2-4 streams become bit-identical
@@ -53,7 +53,7 @@ def _compile(cmd, verbose=False):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(os.path.dirname(HERE), "include", "o2345.h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []
@@ -89,6 +89,24 @@ def build_variant(tag, defines, packed_fp32=False):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, SOURCES))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [os.path.join(objdir, s + ".o") for s in SOURCES])
+    return lib
+
+
+def build_tiles_variant():
+    """libo2345_hip_tiles.so: the product objects + csrc/color_mfma.hip recompiled with -DO2345_TILES_KERNEL (k_color_mfma, the (point, view)-column colour
+    kernel that lost against k_color_pts: test-only since round 4).  tests/test_gpu_parity.py::test_color_points loads it next to the product library."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    build()
+    objdir, vdir = os.path.join(HERE, "build"), os.path.join(HERE, "build_tiles")
+    os.makedirs(vdir, exist_ok=True)
+    src, obj = os.path.join(CSRC, "color_mfma.hip"), os.path.join(vdir, "color_mfma.hip.o")
+    lib = os.path.join(HERE, "libo2345_hip_tiles.so")
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(os.path.dirname(HERE), "include", "o2345.h")]
+    if _stale(obj, [src] + headers + [os.path.abspath(__file__)]):
+        _compile([hipcc] + FLAGS + EXTRA_FLAGS.get("color_mfma.hip", []) + ["-DO2345_TILES_KERNEL", "-c", src, "-o", obj])
+    objs = [obj if s_ == "color_mfma.hip" else os.path.join(objdir, s_ + ".o") for s_ in SOURCES]
+    if _stale(lib, objs):
+        _compile([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     return lib
 
 

@@ -5,7 +5,8 @@ import numpy as np
 import torch
 
 from . import config, ops
-from .weights import COSTREG_LAYERS, pack_sparse_conv_x3
+from . import weights
+from .weights import COSTREG_LAYERS
 
 
 class CostRegNet:
@@ -13,17 +14,31 @@ class CostRegNet:
         """precision "f16x3" (default, config.py): convolutions on the matrix cores (csrc/sparse_mfma.hip); "fp32": thread-per-row
         fp32 VALU kernel (csrc/sparse.hip)."""
         self.x3 = config.color_precision(precision) == "f16x3"
-        t = lambda a: torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a), dtype=torch.float32).contiguous().to(device)
+
+        def t(a):                     # device-resident parameters stay where they are (no host round trip per tensor)
+            if torch.is_tensor(a):
+                return a.detach().to(device=device, dtype=torch.float32).contiguous()
+            return torch.as_tensor(np.asarray(a), dtype=torch.float32).contiguous().to(device)
         self.p = {}
         for name, _, _ in COSTREG_LAYERS:
             self.p[name] = (t(state_dict[f"{prefix}{name}.net.0.kernel"]), t(state_dict[f"{prefix}{name}.net.1.weight"]),
                             t(state_dict[f"{prefix}{name}.net.1.bias"]))
-        self.xblob = {name: torch.from_numpy(pack_sparse_conv_x3(self.p[name][0])).to(device) for name, _, _ in COSTREG_LAYERS} if self.x3 else {}
+        self.xblob = {}
+        if self.x3:
+            # ONE device -> host copy of all ten kernels (0.9 MB), then the packed operands (weights.cached_pack: memoised on disk by content)
+            ks = [self.p[name][0] for name, _, _ in COSTREG_LAYERS]
+            flat = torch.cat([k.reshape(-1) for k in ks]).cpu().numpy()
+            off = 0
+            for (name, _, _), k in zip(COSTREG_LAYERS, ks):
+                kn = flat[off:off + k.numel()].reshape(tuple(k.shape))
+                off += k.numel()
+                self.xblob[name] = torch.from_numpy(weights.packed_sparse_conv_x3(kn)).to(device)
 
     def _blk(self, name, x, mode, in_grid, in_cells, out_coords, ts_out, skip=None):
         K, g, b = self.p[name]
         if self.x3:
-            y = ops.sparse_conv3d_x3(mode, x, in_grid, in_cells, out_coords, ts_out, self.xblob[name], K.shape[2])
+            # mode 0 layers run on the level's own coordinate list (in_grid was built from out_coords): the identity-row guarantee of the brick kernel
+            y = ops.sparse_conv3d_x3(mode, x, in_grid, in_cells, out_coords, ts_out, self.xblob[name], K.shape[2], identity_rows=(mode == 0))
         else:
             y = ops.sparse_conv3d(mode, x, in_grid, in_cells, out_coords, ts_out, K)
         return ops.bn_act_rows(y, g, b, eps=1e-5, slope=0.0, abs_gamma=False, skip=skip)

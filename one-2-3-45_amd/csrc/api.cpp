@@ -13,7 +13,31 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace o2345
 
+#include <stddef.h>
+
 extern "C" {
 const char* o2345_last_error(void) { return o2345::g_err; }
-int o2345_version(void) { return 150; }     // 1.5: o2345_list_sort_by_visibility (render work-list grouped by visibility); 1.4: color stats, bf16 entry removed; 1.2: O2345RenderIO.t_rand + o2345_ray_coarse_jitter (perturb > 0); 1.3: o2345_conv2d family
+int o2345_version(void) { return 200; }     // 2.0: see include/o2345.h (1.5: o2345_list_sort_by_visibility; 1.4: color stats, bf16 entry removed; 1.3: o2345_conv2d family; 1.2: t_rand)
+
+const char* o2345_knobs(void) {
+    static const struct Text { char s[160]; Text() { const o2345::Knobs& k = o2345::knobs();
+        snprintf(s, sizeof s, "list_sort=%d sparse_brick=%d flat_sched=%d color_tiles=%d color_sched=%d", k.list_sort, k.sparse_brick, k.flat_sched, k.color_tiles, k.color_sched); } } t;
+    return t.s;
+}
+
+// layout of O2345RenderIO as compiled into this library, in declaration order (include/o2345.h); the ctypes binding compares its own struct with it
+size_t o2345_render_io_size(void) { return sizeof(O2345RenderIO); }
+int o2345_render_io_layout(size_t* offsets_host, int n) {
+#define F(name) offsetof(O2345RenderIO, name)
+    static const size_t off[] = {
+        F(sdf_blob), F(color_x3_blob), F(color_mfma_blob), F(vol_cl), F(maskvol), F(cmaps), F(proj), F(cam_pos), F(D), F(V), F(H), F(W),
+        F(rays_o), F(rays_d), F(near_ray), F(far_ray), F(query_cam), F(t_rand), F(R), F(n_samples), F(n_importance), F(sdf_mode),
+        F(near), F(far), F(sample_dist), F(inv_s), F(alpha_inter_ratio), F(background),
+        F(mid_z), F(dists), F(pm), F(sdf), F(grad), F(rgb), F(nviews), F(color), F(depth), F(weights), F(cdf), F(weights_sum), F(weights_max),
+        F(depth_var), F(alpha_sum), F(grad_err), F(color_mask), F(z_vals), F(scalars), F(color_stats)};
+#undef F
+    const int nf = (int)(sizeof off / sizeof off[0]);
+    for (int i = 0; i < n && i < nf && offsets_host; ++i) offsets_host[i] = off[i];
+    return nf;
+}
 }

@@ -24,6 +24,9 @@
 
 namespace o2345 {
 
+// k_color_mfma is a TEST-ONLY build variant since round 4 (-DO2345_TILES_KERNEL, build.build_variant("tiles", ["-DO2345_TILES_KERNEL"])): it
+// loses against k_color_pts at every view count (45.7 - 47.7 vs 36.1 - 37.0 ms at 8 views, 52.3 vs 37.1 ms at 32) and the product library does not carry it.
+#ifdef O2345_TILES_KERNEL
 template <int G, bool X3>
 __global__ __launch_bounds__(768) void k_color_mfma(ColorMArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -287,6 +290,8 @@ __global__ __launch_bounds__(768) void k_color_mfma(ColorMArgs a) {
     }
 }
 
+#endif  // O2345_TILES_KERNEL
+
 }  // namespace o2345
 
 using namespace o2345;
@@ -299,50 +304,46 @@ int o2345_color_x3_blob_floats(void) { return CX_TOTAL2; }
 static int color_mfma_launch(bool x3, const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
                              const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
                              const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
-                             const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream) {
-    O2345_REQUIRE(blob && vol_cl && maskvol && cmaps && proj && cam_pos && pts && out_rgb, "color_points_mfma: null pointer");
-    O2345_REQUIRE((query_cam != nullptr) != (normals != nullptr), "color_points_mfma: give exactly one of query_cam / normals");
-    O2345_REQUIRE(V >= 1 && V <= 255, "color_points_mfma: V must be in [1,255] (valid-view counts are stored as uint8; got %d)", V);
+                             const float* normals, float* out_rgb, uint8_t* out_nviews, unsigned long long* stats_dev, void* stream) {
+    O2345_REQUIRE(blob && vol_cl && maskvol && cmaps && proj && cam_pos && pts && out_rgb, "color_points: null pointer");
+    O2345_REQUIRE((query_cam != nullptr) != (normals != nullptr), "color_points: give exactly one of query_cam / normals");
+    O2345_REQUIRE(V >= 1 && V <= 255, "color_points: V must be in [1,255] (valid-view counts are stored as uint8; got %d)", V);
     if (n <= 0 && !n_dev) return 0;
-    {
-        // Two kernels compute the same function: k_color_pts (columns = points, any view count; views that see none of a
-        // tile's points are skipped) and k_color_mfma (columns = (point, view) pairs, view count padded to a power of two <= 32: every pair is
-        // evaluated).  Measured on MI355X (tools/ab_sched.py, split-f16 form): 8 views / 29.5 M points 41.7 vs 47.7 ms, 32 views / 8.3 M points
-        // 46.3 vs 52.3 ms -> k_color_pts is the default for every view count; O2345_COLOR_KERNEL=tiles selects k_color_mfma (A/B runs, tests).
-        bool use_pts = true;
-        const char* e = getenv("O2345_COLOR_KERNEL");
-        if (e && e[0] == 't' && V <= 32) use_pts = false;
-        if (use_pts)
-            return color_pts_launch(x3 ? 1 : 0, blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals,
-                                    out_rgb, out_nviews, stream);
-    }
-    ColorMArgs a{blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews};
-    a.sched = color_sched_mode();
-    int G = 4;
-    while (G < V) G <<= 1;
-    const int n_cu = cu_count();
-    const int threads = 768, ppt = 32 / G;
-    const long long per_block = (long long)(threads / 64) * ppt;
-    long long want = n_dev ? n_cu : (n + per_block - 1) / per_block;
-    const unsigned grid = persistent_grid(want, n_cu);
-    const size_t lds = (size_t)((x3 ? CX_TOTAL : CM_TOTAL) + (threads / 64) * ppt * (2 * 64 + 4)) * sizeof(float);
-    hipStream_t s = (hipStream_t)stream;
+#ifdef O2345_TILES_KERNEL
+    // test-only variant: O2345_COLOR_KERNEL=tiles selects k_color_mfma (columns = (point, view) pairs, view count padded to a power of two <= 32, every
+    // pair evaluated) -- the A/B partner of k_color_pts in tests/test_gpu_parity.py::test_color_points and tools/ab_color.py
+    if (knobs().color_tiles && V <= 32) {
+        ColorMArgs a{blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews};
+        a.sched = color_sched_mode();
+        int G = 4;
+        while (G < V) G <<= 1;
+        const int n_cu = cu_count();
+        const int threads = 768, ppt = 32 / G;
+        const long long per_block = (long long)(threads / 64) * ppt;
+        long long want = n_dev ? n_cu : (n + per_block - 1) / per_block;
+        const unsigned grid = persistent_grid(want, n_cu);
+        const size_t lds = (size_t)((x3 ? CX_TOTAL : CM_TOTAL) + (threads / 64) * ppt * (2 * 64 + 4)) * sizeof(float);
+        hipStream_t s = (hipStream_t)stream;
 #define O2345_CM_CASE(GG, XX)                                                                                              \
     if (G == GG && x3 == XX) {                                                                                             \
-        (void)hipFuncSetAttribute((const void*)k_color_mfma<GG, XX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        O2345_ENSURE_LDS((k_color_mfma<GG, XX>), lds);                                                                     \
         hipLaunchKernelGGL((k_color_mfma<GG, XX>), dim3(grid), dim3(threads), lds, s, a);                                  \
     }
-    O2345_CM_CASE(4, false) O2345_CM_CASE(8, false) O2345_CM_CASE(16, false) O2345_CM_CASE(32, false)
-    O2345_CM_CASE(4, true) O2345_CM_CASE(8, true) O2345_CM_CASE(16, true) O2345_CM_CASE(32, true)
+        O2345_CM_CASE(4, false) O2345_CM_CASE(8, false) O2345_CM_CASE(16, false) O2345_CM_CASE(32, false)
+        O2345_CM_CASE(4, true) O2345_CM_CASE(8, true) O2345_CM_CASE(16, true) O2345_CM_CASE(32, true)
 #undef O2345_CM_CASE
-    return check_launch("color_points_mfma");
+        return check_launch("color_points (tiles kernel)");
+    }
+#endif
+    return color_pts_launch(x3 ? 1 : 0, blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals,
+                            out_rgb, out_nviews, stats_dev, stream);
 }
 
 int o2345_color_points_mfma(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
                             const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
                             const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
-                            const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream) {
-    return color_mfma_launch(false, blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews, stream);
+                            const float* normals, float* out_rgb, uint8_t* out_nviews, unsigned long long* stats_dev, void* stream) {
+    return color_mfma_launch(false, blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews, stats_dev, stream);
 }
 
 // Projector.compute (query_cam) / compute_view_independent (normals) materialised: geometry_feat [P,16], rgb_feat [V,P,59], ray_diff [V,P,4],
@@ -372,8 +373,8 @@ int o2345_color_from_features(const float* blob, int x3, const float* geometry_f
 int o2345_color_points_x3(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
                           const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
                           const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
-                          const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream) {
-    return color_mfma_launch(true, blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews, stream);
+                          const float* normals, float* out_rgb, uint8_t* out_nviews, unsigned long long* stats_dev, void* stream) {
+    return color_mfma_launch(true, blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews, stats_dev, stream);
 }
 
 }  // extern "C"

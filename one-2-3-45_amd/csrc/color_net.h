@@ -63,7 +63,7 @@ struct ColorMArgs {
     const float* f_rgb;       // [V,P,59]  colours (3) | features (56)
     const float* f_rdiff;     // [V,P,4]
     const float* f_mask;      // [V,P]     non-zero = the projection is valid
-    unsigned long long* stats;  // optional device counters (o2345_color_stats_enable): [0] += (tile, view) pairs evaluated in pass A, [1] += in pass B,
+    unsigned long long* stats;  // optional caller-owned device counters (stats_dev of o2345_color_points_*): [0] += (tile, view) pairs evaluated in pass A, [1] += in pass B,
                               // [2] += tiles, [3] += tiles that evaluated every view in pass B because one of their points has no visible view
     int sched;                // scheduling knobs (O2345_COLOR_SCHED; default 10 = bits 1 + 3, measured on MI355X with tools/ab_sched.py):
                               //   bit 0  static wave priority by SIMD slot (the k-th wave of a SIMD runs at priority k): no gain
@@ -73,10 +73,7 @@ struct ColorMArgs {
                               //          skipping a tile's cost depends on where its rays look: -1 % at 8 views, -20 % at 32 views
 };
 
-inline int color_sched_mode() {
-    const char* e = getenv("O2345_COLOR_SCHED");
-    return e ? atoi(e) : 10;
-}
+inline int color_sched_mode() { return knobs().color_sched; }
 #if defined(__HIPCC__)
 __device__ __forceinline__ void set_wave_prio(int p) {       // s_setprio takes an immediate
     switch (p) {
@@ -289,7 +286,7 @@ __device__ __forceinline__ ViewGeom view_geom(const ColorMArgs& a, int v, float 
 
 #endif
 
-// csrc/color_pts.hip: the points-as-columns kernel (default); O2345_COLOR_KERNEL=tiles selects k_color_mfma (csrc/color_mfma.hip)
+// csrc/color_pts.hip: the points-as-columns kernel (the product kernel; k_color_mfma of csrc/color_mfma.hip exists only in -DO2345_TILES_KERNEL test builds)
 int project_features_launch(const float* vol_cl, const float* maskvol, int D, const float* cmaps, const float* proj, const float* cam_pos, int V, int H, int W,
                             const float* pts, long long n, const float* query_cam, const float* normals, float* geo, float* rgb_feat, float* rdiff, float* mask,
                             void* stream);
@@ -297,6 +294,6 @@ int color_feats_launch(int x3, const float* blob, const float* geo, const float*
                        float* out_rgb, uint8_t* out_nviews, void* stream);
 int color_pts_launch(int x3, const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps, const float* proj,
                      const float* cam_pos, int V, int H, int W, const float* pts, const int32_t* index, const int32_t* n_dev, long long n,
-                     const float* query_cam, const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
+                     const float* query_cam, const float* normals, float* out_rgb, uint8_t* out_nviews, unsigned long long* stats_dev, void* stream);
 
 }  // namespace o2345

@@ -361,17 +361,14 @@ __global__ __launch_bounds__(CP_THREADS) void k_color_pts(ColorMArgs a) {
 
 namespace o2345 {
 
-// work counters of the colour kernel (diagnostics for bench.py's matrix-pipe utilisation: how many (tile, view) pairs were evaluated)
-static unsigned long long* g_color_stats = nullptr;
-unsigned long long* color_stats_buffer() { return g_color_stats; }
-
 // launcher shared by o2345_color_points_mfma / o2345_color_points_x3 (csrc/color_mfma.hip decides which kernel runs)
 int color_pts_launch(int x3, const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps, const float* proj,
                            const float* cam_pos, int V, int H, int W, const float* pts, const int32_t* index, const int32_t* n_dev,
-                           long long n, const float* query_cam, const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream) {
+                           long long n, const float* query_cam, const float* normals, float* out_rgb, uint8_t* out_nviews,
+                           unsigned long long* stats_dev /* optional, caller-owned work counters [4] */, void* stream) {
     ColorMArgs a{blob, vol_cl, maskvol, D, cmaps, proj, cam_pos, V, H, W, pts, index, n_dev, n, query_cam, normals, out_rgb, out_nviews};
     a.sched = color_sched_mode();
-    a.stats = g_color_stats;
+    a.stats = stats_dev;
     const int n_cu = cu_count();
     const int threads = CP_THREADS;
     const long long per_block = (long long)(threads / 64) * 32;
@@ -380,10 +377,10 @@ int color_pts_launch(int x3, const float* blob, const float* vol_cl, const float
     const size_t lds = (size_t)(x3 ? (CX_A_END + CM_W_S - CM_BIAS0) + 4 + 2 * 9 * 512 : CM_W_S + 4 + 2 * 72 * 64) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (x3) {
-        O2345_HIP(hipFuncSetAttribute((const void*)k_color_pts<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        O2345_ENSURE_LDS((k_color_pts<true, false>), lds);
         hipLaunchKernelGGL((k_color_pts<true, false>), dim3(grid), dim3(threads), lds, s, a);
     } else {
-        O2345_HIP(hipFuncSetAttribute((const void*)k_color_pts<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        O2345_ENSURE_LDS((k_color_pts<false, false>), lds);
         hipLaunchKernelGGL((k_color_pts<false, false>), dim3(grid), dim3(threads), lds, s, a);
     }
     return check_launch("color_points (points-as-columns kernel)");
@@ -460,37 +457,13 @@ int color_feats_launch(int x3, const float* blob, const float* geo, const float*
     const size_t lds = (size_t)(x3 ? (CX_A_END + CM_W_S - CM_BIAS0) + 4 + 2 * 9 * 512 : CM_W_S + 4 + 2 * 72 * 64) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (x3) {
-        O2345_HIP(hipFuncSetAttribute((const void*)k_color_pts<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        O2345_ENSURE_LDS((k_color_pts<true, true>), lds);
         hipLaunchKernelGGL((k_color_pts<true, true>), dim3(grid), dim3(CP_THREADS), lds, s, a);
     } else {
-        O2345_HIP(hipFuncSetAttribute((const void*)k_color_pts<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        O2345_ENSURE_LDS((k_color_pts<false, true>), lds);
         hipLaunchKernelGGL((k_color_pts<false, true>), dim3(grid), dim3(CP_THREADS), lds, s, a);
     }
     return check_launch("color_from_features");
 }
 
 }  // namespace o2345
-
-extern "C" {
-
-// Diagnostics: enable != 0 allocates (once) and zeroes four device counters that every following k_color_pts launch of this process adds to;
-// enable == 0 stops counting.  o2345_color_stats_read copies them to the host (synchronises the stream):
-// out[0] = (32-point tile, view) pairs evaluated in pass A, out[1] = in pass B, out[2] = tiles, out[3] = tiles that evaluated every view in pass B.
-int o2345_color_stats_enable(int enable, void* stream) {
-    using namespace o2345;
-    if (!enable) { g_color_stats = nullptr; return 0; }
-    static unsigned long long* buf = nullptr;
-    if (!buf) O2345_HIP(hipMalloc(&buf, 4 * sizeof(unsigned long long)));
-    O2345_HIP(hipMemsetAsync(buf, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));
-    g_color_stats = buf;
-    return 0;
-}
-int o2345_color_stats_read(unsigned long long* out4, void* stream) {
-    using namespace o2345;
-    O2345_REQUIRE(out4 && g_color_stats, "color_stats_read: counters are not enabled");
-    O2345_HIP(hipMemcpyAsync(out4, g_color_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    O2345_HIP(hipStreamSynchronize((hipStream_t)stream));
-    return 0;
-}
-
-}  // extern "C"

@@ -1,5 +1,7 @@
 // Shared helpers for the o2345 HIP library (gfx950 only).
 #pragma once
+#include "../../include/o2345.h"      // every translation unit sees the public prototypes: an entry point that drifts from the header does not compile
+#include <atomic>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -85,12 +87,51 @@ __device__ __forceinline__ int block_prefix(bool pred, int* lds_wave_tot /*[NWAV
 }
 
 
+// Debug / A-B knobs of the library, read from the environment ONCE (first use; function-local static: thread-safe, and no getenv on a launch path --
+// getenv is not safe against a concurrent setenv, and the library is used from one host thread per stream / device):
+//   O2345_LIST_SORT=0     render call: keep the occupied-point list in emission order (no grouping by view-visibility signature)
+//   O2345_COLOR_SCHED=n   scheduling bits of the colour kernel (color_net.h), default 10
+//   O2345_SPARSE_BRICK=0  finest sparse convolution in the gather form instead of the LDS-tiled brick form
+//   O2345_FLAT_SCHED=1    persistent network kernels: flat block-interleaved tile schedule (odd grid) instead of one eighth of the list per XCD
+//   O2345_COLOR_KERNEL=tiles  (only in a -DO2345_TILES_KERNEL test build) the (point, view)-column colour kernel instead of k_color_pts
+struct Knobs {
+    bool list_sort, sparse_brick, flat_sched, color_tiles;
+    int color_sched;
+};
+inline const Knobs& knobs() {
+    static const Knobs k = [] {
+        auto is = [](const char* name, char c) { const char* e = getenv(name); return e && e[0] == c; };
+        const char* cs = getenv("O2345_COLOR_SCHED");
+        return Knobs{!is("O2345_LIST_SORT", '0'), !is("O2345_SPARSE_BRICK", '0'), is("O2345_FLAT_SCHED", '1'), is("O2345_COLOR_KERNEL", 't'), cs ? atoi(cs) : 10};
+    }();
+    return k;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, raised at most once per (call site, device, size): call sites keep one `MaxLds` object
+// (function-local static).  Replaces a hipFuncSetAttribute on every launch.
+struct MaxLds {
+    std::atomic<int> cur[64];
+    MaxLds() { for (auto& c : cur) c.store(0, std::memory_order_relaxed); }
+    hipError_t ensure(const void* func, size_t bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if ((int)bytes <= cur[dev].load(std::memory_order_acquire)) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) cur[dev].store((int)bytes, std::memory_order_release);
+        return e;
+    }
+};
+#define O2345_ENSURE_LDS(kernel, bytes)                                                   \
+    do {                                                                                  \
+        static o2345::MaxLds max_lds_;                                                    \
+        O2345_HIP(max_lds_.ensure((const void*)(kernel), (size_t)(bytes)));               \
+    } while (0)
+
 // host side: grid of a persistent network kernel.  O2345_FLAT_SCHED=1 (debug / A-B knob) makes the grid odd, which selects the
 // flat block-interleaved schedule in tile_schedule() below.
 inline unsigned persistent_grid(long long want, int n_cu) {
     unsigned g = (unsigned)(want < n_cu ? want : n_cu);
-    const char* e = getenv("O2345_FLAT_SCHED");
-    if (e && e[0] == '1' && g > 8 && (g & 7) == 0) --g;
+    if (knobs().flat_sched && g > 8 && (g & 7) == 0) --g;
     return g;
 }
 

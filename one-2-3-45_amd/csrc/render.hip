@@ -5,7 +5,7 @@
 // per-ray lists are sample-major ([S][R]) so every access of the wave is a coalesced row segment; the SDF network
 // is called on flat point lists (occupied points compacted with a ballot/popcount prefix into an index list that
 // the MFMA kernel consumes with a device-side count -- no host synchronisation anywhere in a render call).
-#include "common.h"
+#include "common.h"                    // pulls in include/o2345.h: O2345RenderIO is declared THERE only (layout-checked by the binding at load time)
 #include "render_math.h"
 
 namespace o2345 {
@@ -14,12 +14,16 @@ namespace o2345 {
 // t_rand (optional): the reference's stratified jitter (sparse_neus_renderer.py:506-515).  The reference draws
 // t_rand = torch.rand(z_vals.shape) on the HOST ([R][S], ray-major) and sets z = lower + (upper - lower) * t_rand with
 // lower/upper the midpoints to the neighbouring coarse samples; the caller hands the same tensor over, so the path is
-// bit-reproducible under torch.manual_seed.
-__global__ __launch_bounds__(256) void k_ray_coarse(RayGeom g, float near, float far, int S, const float* __restrict__ t_rand,
-                                                    float* __restrict__ z, float* __restrict__ pts) {
+// bit-reproducible under torch.manual_seed.  msk (optional, [S][R] bytes): 1 where the sample point lies in an occupied voxel of the mask volume
+// (what up_sample asks of every sample, :84-88) -- kept next to z / sdf from here on, so that no later kernel has to gather it again.
+__global__ __launch_bounds__(256) void k_ray_coarse(RayGeom g, float near, float far, const float* __restrict__ near_ray,
+                                                    const float* __restrict__ far_ray, int S, const float* __restrict__ t_rand,
+                                                    float* __restrict__ z, float* __restrict__ pts, const float* __restrict__ maskvol, int D,
+                                                    uint8_t* __restrict__ msk) {
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= (long long)S * g.R) return;
     const int s = (int)(p / g.R), r = (int)(p % g.R);
+    if (near_ray) { near = near_ray[r]; far = far_ray[r]; }      // the reference's [N_rays, 1] near / far (:486-490): the same expression per ray
     float zz = near + (far - near) * linspace_at(0.f, 1.f, S, s);
     if (t_rand) {
         const float zp = near + (far - near) * linspace_at(0.f, 1.f, S, s > 0 ? s - 1 : 0);
@@ -32,6 +36,7 @@ __global__ __launch_bounds__(256) void k_ray_coarse(RayGeom g, float near, float
     float x, y, w;
     ray_point(g, r, zz, x, y, w);
     pts[3 * p] = x; pts[3 * p + 1] = y; pts[3 * p + 2] = w;
+    if (msk) msk[p] = mask_at(maskvol, D, x, y, w) > 0.f ? 1 : 0;
 }
 
 // Occupied points are appended to a global list (order inside the list is irrelevant for the results: they are scattered back
@@ -57,29 +62,6 @@ __device__ __forceinline__ void append_wave(const ValidBits& bits, int n_samples
     }
 }
 
-__global__ __launch_bounds__(256) void k_ray_upsample(RayGeom g, const float* __restrict__ z, const float* __restrict__ sdf, int S,
-                                                      float inv_s, const float* __restrict__ maskvol, int D,
-                                                      float* __restrict__ wbuf, int n_imp, float* __restrict__ new_z,
-                                                      float* __restrict__ new_pts, float* __restrict__ new_sdf,
-                                                      int* __restrict__ list, int* __restrict__ count) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    const bool live = r < g.R;
-    if (live) upsample_ray(g, r, z, sdf, S, inv_s, maskvol, D, wbuf, n_imp, new_z);
-    ValidBits bits{};
-    int cnt = 0;
-    for (int t = 0; t < n_imp; ++t) {
-        const int slot = t * g.R + r;
-        if (live) {
-            float x, y, w;
-            ray_point(g, r, new_z[slot], x, y, w);
-            new_pts[3 * (size_t)slot] = x; new_pts[3 * (size_t)slot + 1] = y; new_pts[3 * (size_t)slot + 2] = w;
-            new_sdf[slot] = 100.f;                               // cat_z_vals default outside the mask (:135)
-            if (mask_at(maskvol, D, x, y, w) > 0.f) { bits.w[t >> 5] |= 1u << (t & 31); ++cnt; }
-        }
-    }
-    append_wave(bits, n_imp, cnt, g.R, r, list, count);
-}
-
 // cat_z_vals quirk (:137): the SDF of the new points is evaluated only if MORE THAN ONE of them is inside the mask
 __global__ void k_quirk_min2(int* count) { if (*count <= 1) *count = 0; }
 // render_core quirk (:222-223): with no valid point at all, the first 100 points of the chunk (ray 0, samples 0..99
@@ -91,54 +73,256 @@ __global__ void k_quirk_first100(int* count, int* list, int R, int S) {
     if (t == 0) *count = (100 < S ? 100 : S);
 }
 
-__global__ __launch_bounds__(256) void k_ray_merge(int R, float* z, float* sdf, int S, float* new_z, float* new_sdf, int n_new) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < R) merge_ray(r, R, z, sdf, S, new_z, new_sdf, n_new);
-}
+// ---- one round of the hierarchical sampler, 64 rays per wave, the rays' lists staged in LDS -------------------------------------------------------
+// Round-3 kernels walked a ray's samples straight from the sample-major global lists: every step of the serial chains (transmittance, CDF walk,
+// back-to-front merge) was a DEPENDENT trip to L2 / HBM, 60 - 110 of them per ray and launch -- 81 / 40 / 95 us per launch for one 512-ray chunk
+// of the reference's val loop and 2.9 ms per 262,144 rays with one lane per ray.  Here a wave first copies the lists of its 64 rays into LDS with
+// every load in flight (rows of 256 bytes, lane = ray: a[row * 64 + lane]; a lane only ever touches its own column, so there are no bank conflicts
+// and no barriers), runs the chains out of LDS, and writes results back as whole rows.  Three things are fused on top of that:
+//   * cat_z_vals of the PREVIOUS round (merge of its 16 new samples, now with their SDF values) happens in LDS at the start of the next kernel:
+//     the merged list is written back once, and the separate merge launch with its two passes over the lists is gone;
+//   * the occupancy flag of every sample point travels with the list (one byte per sample, produced where the point is produced) instead of
+//     being gathered from the mask volume again in every round;
+//   * the last merge is fused with render_core's head (mid points, section lengths, occupancy, defaults, occupied-point list).
+// The arithmetic of every chain is that of render_math.h (shared with the host-check build), in the same order.
+constexpr int RT = 64;                              // rays per wave / tile
+constexpr int RAY_LDS_ROW_BYTES = RT * (4 + 4 + 1);  // z | sdf (later: section weight) | occupancy flag
 
-// render_core head (:204-218): section lengths, mid points, occupancy of the mid points, defaults, valid list
-__global__ __launch_bounds__(256) void k_ray_finalize(RayGeom g, const float* __restrict__ z, int S, float sample_dist,
-                                                      const float* __restrict__ maskvol, int D, float* __restrict__ mid_z,
-                                                      float* __restrict__ dists, float* __restrict__ pts,
-                                                      float* __restrict__ pm, float* __restrict__ sdf, float* __restrict__ grad,
-                                                      float* __restrict__ rgb, int* __restrict__ list, int* __restrict__ count,
-                                                      int defaults_everywhere) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    const bool live = r < g.R;
-    ValidBits bits{};
-    int cnt = 0;
+struct RoundArgs {
+    RayGeom g;
+    float* z; float* sdf; uint8_t* msk;              // the lists [rows][R] (msk may be null: occupancy is then gathered while staging)
+    int S;                                           // samples per ray in the lists (before the merge)
+    const float* new_z; const float* new_sdf; const uint8_t* new_msk; int n_new;      // previous round's samples to merge first (n_new = 0: none)
+    const float* maskvol; int D;
+    // upsample
+    float inv_s; int n_imp;
+    float* out_z; float* out_pts; float* out_sdf; uint8_t* out_msk; int* list; int* count;
+    // finalize
+    float sample_dist;
+    float* mid_z; float* dists; float* pts; float* pm; float* o_sdf; float* grad; float* rgb; int defaults_everywhere;
+};
+
+struct LdsRay {                                      // accessor of upsample_core (render_math.h) on the staged tile
+    float* zL; float* sL; const uint8_t* mL; int lane; int tmp_row;
+    __device__ __forceinline__ float z(int s) const { return zL[s * RT + lane]; }
+    __device__ __forceinline__ float sdf(int s) const { return sL[s * RT + lane]; }
+    __device__ __forceinline__ float msk(int s, float) const { return (float)mL[s * RT + lane]; }
+    __device__ __forceinline__ void set_w(int s, float v) { sL[s * RT + lane] = v; }      // sdf[s] has been consumed when section s is done
+    __device__ __forceinline__ float w(int s) const { return sL[s * RT + lane]; }
+    __device__ __forceinline__ void out(int t, float v) { zL[(tmp_row + t) * RT + lane] = v; }   // new depths: parked in the free rows behind the list
+};
+struct LdsMerge {                                    // accessor of merge_core_fixed
+    float* zL; float* sL; uint8_t* mL; int lane;
+    __device__ __forceinline__ float z(int i) const { return zL[i * RT + lane]; }
+    __device__ __forceinline__ float sdf(int i) const { return sL[i * RT + lane]; }
+    __device__ __forceinline__ unsigned tag(int i) const { return mL[i * RT + lane]; }
+    __device__ __forceinline__ void put(int i, float zv, float sv, unsigned t) { zL[i * RT + lane] = zv; sL[i * RT + lane] = sv; mL[i * RT + lane] = (uint8_t)t; }
+};
+
+constexpr int RM_UPSAMPLE = 0, RM_FINALIZE = 1, RM_MERGE_ONLY = 2;
+constexpr int NFIX = 16;                             // new samples per round held in registers (n_importance / 4 of the released configuration)
+
+template <int MODE, bool MERGE>
+__global__ __launch_bounds__(RT) void k_ray_round(RoundArgs a) {
+    extern __shared__ float lds[];
+    const int R = a.g.R, lane = threadIdx.x;
+    const int r = blockIdx.x * RT + lane;
+    const bool live = r < R;
+    const int rr = live ? r : R - 1;                 // lanes past the last ray shadow it (reads only)
+    const int rows = a.S + (MERGE ? NFIX : 0) + (MODE == RM_UPSAMPLE ? a.n_imp : 0);
+    float* zL = lds;
+    float* sL = zL + rows * RT;
+    uint8_t* mL = reinterpret_cast<uint8_t*>(sL + rows * RT);
+    int S = a.S;
+    // ---- stage the lists: independent loads, 8 rows in flight per array
+#pragma unroll 8
     for (int s = 0; s < S; ++s) {
-        const size_t p = (size_t)s * g.R + r;
-        if (live) {
-            const float z0 = z[p];
-            const float d = (s + 1 < S) ? z[p + g.R] - z0 : sample_dist;
-            const float mz = z0 + d * 0.5f;
-            float x, y, w;
-            ray_point(g, r, mz, x, y, w);
-            const float m = mask_at(maskvol, D, x, y, w);
-            dists[p] = d; mid_z[p] = mz; pm[p] = m;
-            pts[3 * p] = x; pts[3 * p + 1] = y; pts[3 * p + 2] = w;
-            if (m > 0.f) { bits.w[s >> 5] |= 1u << (s & 31); ++cnt; }
-            if (!(m > 0.f) || defaults_everywhere) {
-                // the reference's defaults (:231: sdf = 100, gradients = colours = 0).  Inside o2345_render_rays occupied points are ALWAYS overwritten by the
-                // network kernels that consume the list (every list entry is evaluated), so only unoccupied points need them there: 28 bytes less per
-                // occupied point.  The public stage entry initialises every slot (a caller may evaluate only part of the list).
-                sdf[p] = 100.f;
-                grad[3 * p] = 0.f; grad[3 * p + 1] = 0.f; grad[3 * p + 2] = 0.f;
-                rgb[3 * p] = 0.f; rgb[3 * p + 1] = 0.f; rgb[3 * p + 2] = 0.f;
+        zL[s * RT + lane] = a.z[(size_t)s * R + rr];
+        sL[s * RT + lane] = a.sdf[(size_t)s * R + rr];
+    }
+    const bool need_mask = MODE == RM_UPSAMPLE;
+    if (need_mask || (MERGE && a.msk)) {
+        if (a.msk) {
+#pragma unroll 8
+            for (int s = 0; s < S; ++s) mL[s * RT + lane] = a.msk[(size_t)s * R + rr];
+        } else {
+#pragma unroll 8
+            for (int s = 0; s < S; ++s) {
+                float x, y, w;
+                ray_point(a.g, rr, zL[s * RT + lane], x, y, w);
+                mL[s * RT + lane] = mask_at(a.maskvol, a.D, x, y, w) > 0.f ? 1 : 0;
             }
         }
     }
-    append_wave(bits, S, cnt, g.R, r, list, count);
+    // ---- cat_z_vals of the previous round's samples, in LDS
+    if (MERGE) {
+        float nz[NFIX], ns[NFIX];
+        unsigned nt[NFIX];
+#pragma unroll
+        for (int j = 0; j < NFIX; ++j) {
+            nz[j] = a.new_z[(size_t)j * R + rr];
+            ns[j] = a.new_sdf[(size_t)j * R + rr];
+            nt[j] = a.new_msk ? a.new_msk[(size_t)j * R + rr] : 0u;
+        }
+        if (need_mask && !a.new_msk) {
+#pragma unroll
+            for (int j = 0; j < NFIX; ++j) {
+                float x, y, w;
+                ray_point(a.g, rr, nz[j], x, y, w);
+                nt[j] = mask_at(a.maskvol, a.D, x, y, w) > 0.f ? 1u : 0u;
+            }
+        }
+        bool sorted = true;
+#pragma unroll
+        for (int j = 0; j + 1 < NFIX; ++j) sorted = sorted && !(nz[j] > nz[j + 1]);
+        LdsMerge m{zL, sL, mL, lane};
+        merge_core_fixed<LdsMerge, NFIX>(m, S, nz, ns, nt, !__any(!sorted));
+        S += NFIX;
+        if (live) {
+#pragma unroll 8
+            for (int s = 0; s < S; ++s) {
+                a.z[(size_t)s * R + r] = zL[s * RT + lane];
+                a.sdf[(size_t)s * R + r] = sL[s * RT + lane];
+            }
+            if (a.msk) {
+#pragma unroll 8
+                for (int s = 0; s < S; ++s) a.msk[(size_t)s * R + r] = mL[s * RT + lane];
+            }
+        }
+    }
+    if (MODE == RM_UPSAMPLE) {
+        // ---- up_sample + sample_pdf (render_math.h upsample_core) out of LDS; the new depths are parked in rows S .. S + n_imp - 1 of zL
+        LdsRay acc{zL, sL, mL, lane, S};
+        upsample_core(acc, S, a.inv_s, a.n_imp);
+        ValidBits bits{};
+        int cnt = 0;
+        for (int t0 = 0; t0 < a.n_imp; t0 += 8) {                       // points, defaults and occupancy of the new samples: 8 gathers in flight
+            float m8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int t = t0 + k < a.n_imp ? t0 + k : a.n_imp - 1;
+                const float zn = zL[(S + t) * RT + lane];
+                float x, y, w;
+                ray_point(a.g, rr, zn, x, y, w);
+                m8[k] = mask_at(a.maskvol, a.D, x, y, w);
+                if (live && t0 + k < a.n_imp) {
+                    const size_t slot = (size_t)t * R + r;
+                    a.out_z[slot] = zn;
+                    a.out_pts[3 * slot] = x; a.out_pts[3 * slot + 1] = y; a.out_pts[3 * slot + 2] = w;
+                    a.out_sdf[slot] = 100.f;                             // cat_z_vals default outside the mask (:135)
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int t = t0 + k;
+                if (live && t < a.n_imp) {
+                    const bool in = m8[k] > 0.f;
+                    if (a.out_msk) a.out_msk[(size_t)t * R + r] = in ? 1 : 0;
+                    if (in) { bits.w[t >> 5] |= 1u << (t & 31); ++cnt; }
+                }
+            }
+        }
+        append_wave(bits, a.n_imp, cnt, R, r, a.list, a.count);
+    } else if (MODE == RM_FINALIZE) {
+        // ---- render_core head (:204-231): section lengths, mid points, occupancy of the MID points, defaults, occupied-point list
+        ValidBits bits{};
+        int cnt = 0;
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            float m8[8], d8[8], z8[8], p8[8][3];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int s = s0 + k < S ? s0 + k : S - 1;
+                const float zc = zL[s * RT + lane];
+                const float d = (s + 1 < S) ? zL[(s + 1) * RT + lane] - zc : a.sample_dist;
+                const float mz = zc + d * 0.5f;
+                ray_point(a.g, rr, mz, p8[k][0], p8[k][1], p8[k][2]);
+                m8[k] = mask_at(a.maskvol, a.D, p8[k][0], p8[k][1], p8[k][2]);
+                d8[k] = d; z8[k] = mz;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int s = s0 + k;
+                if (live && s < S) {
+                    const size_t p = (size_t)s * R + r;
+                    const float m = m8[k];
+                    a.dists[p] = d8[k]; a.mid_z[p] = z8[k]; a.pm[p] = m;
+                    a.pts[3 * p] = p8[k][0]; a.pts[3 * p + 1] = p8[k][1]; a.pts[3 * p + 2] = p8[k][2];
+                    if (m > 0.f) { bits.w[s >> 5] |= 1u << (s & 31); ++cnt; }
+                    if (!(m > 0.f) || a.defaults_everywhere) {
+                        // the reference's defaults (:231: sdf = 100, gradients = colours = 0).  Inside o2345_render_rays occupied points are ALWAYS overwritten by the
+                        // network kernels that consume the list (every list entry is evaluated), so only unoccupied points need them there: 28 bytes less per
+                        // occupied point.  The public stage entry initialises every slot (a caller may evaluate only part of the list).
+                        a.o_sdf[p] = 100.f;
+                        a.grad[3 * p] = 0.f; a.grad[3 * p + 1] = 0.f; a.grad[3 * p + 2] = 0.f;
+                        a.rgb[3 * p] = 0.f; a.rgb[3 * p + 1] = 0.f; a.rgb[3 * p + 2] = 0.f;
+                    }
+                }
+            }
+        }
+        append_wave(bits, S, cnt, R, r, a.list, a.count);
+    }
 }
 
-__global__ __launch_bounds__(256) void k_ray_composite(RayGeom g, int S, const float* __restrict__ mid_z, const float* __restrict__ dists,
+// cat_z_vals for a block size other than NFIX: the plain per-ray merge on the global lists (render_math.h merge_ray), occupancy bytes along
+struct GlobalMergeTag {
+    float* z_; float* sdf_; uint8_t* m_; size_t R; int r;
+    __device__ __forceinline__ float z(int i) const { return z_[(size_t)i * R + r]; }
+    __device__ __forceinline__ float sdf(int i) const { return sdf_[(size_t)i * R + r]; }
+    __device__ __forceinline__ unsigned tag(int i) const { return m_ ? m_[(size_t)i * R + r] : 0u; }
+    __device__ __forceinline__ void put(int i, float zv, float sv, unsigned t) {
+        z_[(size_t)i * R + r] = zv; sdf_[(size_t)i * R + r] = sv;
+        if (m_) m_[(size_t)i * R + r] = (uint8_t)t;
+    }
+};
+__global__ __launch_bounds__(64) void k_ray_merge_any(int R, float* z, float* sdf, uint8_t* msk, int S, const float* new_z, const float* new_sdf,
+                                                      const uint8_t* new_msk, int n_new) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    constexpr int NMAX = 32;
+    float nz[NMAX], ns[NMAX];
+    unsigned nt[NMAX];
+    for (int base = 0; base < n_new; base += NMAX) {
+        const int nb = n_new - base < NMAX ? n_new - base : NMAX;
+        for (int j = 0; j < nb; ++j) {
+            nz[j] = new_z[(size_t)(base + j) * R + r]; ns[j] = new_sdf[(size_t)(base + j) * R + r];
+            nt[j] = new_msk ? new_msk[(size_t)(base + j) * R + r] : 0u;
+        }
+        GlobalMergeTag a{z, sdf, msk, (size_t)R, r};
+        merge_core<GlobalMergeTag, NMAX>(a, S + base, nz, ns, nt, nb);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_ray_composite(RayGeom g, int S, const float* __restrict__ mid_z, const float* __restrict__ dists,
                                                        const float* __restrict__ pm, const float* __restrict__ sdf,
                                                        const float* __restrict__ grad, const float* __restrict__ rgb,
                                                        const uint8_t* __restrict__ nviews, float inv_s, float air, float bg,
                                                        CompositeOut o) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.x * 64 + threadIdx.x;
     if (r < g.R) composite_ray(g, r, S, mid_z, dists, pm, sdf, grad, rgb, nviews, inv_s, air, bg, o);
+}
+
+// per-call scalars of render()'s returned dict (:586-633): sums over the rays in a FIXED order (thread t adds rays t, t + 1024, ... in fp64, then a
+// fixed LDS tree): deterministic, one workgroup, no atomics.  out[0] = alpha_sum.mean(), out[1] = alpha_sum.sum() / (R S) ("alpha_mean"),
+// out[2] = sum grad_err[.,0] / (sum grad_err[.,1] + 1e-5) ("gradient_error_fine"), out[3] = number of list entries the network kernels evaluated.
+__global__ __launch_bounds__(1024) void k_ray_scalars(int R, int S, const float* __restrict__ alpha_sum, const float* __restrict__ grad_err,
+                                                      const int* __restrict__ count, float* __restrict__ out) {
+    __shared__ double red[3][1024];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int r = threadIdx.x; r < R; r += 1024) { a += (double)alpha_sum[r]; b += (double)grad_err[2 * r]; c += (double)grad_err[2 * r + 1]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 512; off; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; red[2][threadIdx.x] += red[2][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (float)(red[0][0] / (double)R);
+        out[1] = (float)(red[0][0] / ((double)R * (double)S));
+        out[2] = (float)(red[1][0] / (red[2][0] + 1e-5));
+        out[3] = (float)*count;
+    }
 }
 
 }  // namespace o2345
@@ -147,77 +331,99 @@ using namespace o2345;
 
 extern "C" {
 
-int o2345_sdf_mlp(int variant, const float* blob, const float* vol_cl, int D, const float* pts, const int32_t* index,
-                  const int32_t* n_dev, long long n, int grid_R, float sign, float* out_sdf, float* out_feat,
-                  float* out_lat, float* out_grad, void* stream);
-int o2345_sdf_mlp_x3(const float* blob, const float* vol_cl, int D, const float* pts, const int32_t* index, const int32_t* n_dev,
-                     long long n, int grid_R, float sign, float* out_sdf, void* stream);
-int o2345_sdf_grad_x3(const float* blob, const float* vol_cl, int D, const float* pts, const int32_t* index, const int32_t* n_dev,
-                      long long n, int grid_R, float sign, float* out_sdf, float* out_grad, void* stream);
-int o2345_color_points_x3(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
-                          const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
-                          const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
-                          const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
-int o2345_color_points(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
-                       const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
-                       const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
-                       const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
-int o2345_color_points_mfma(const float* blob, const float* vol_cl, const float* maskvol, int D, const float* cmaps,
-                            const float* proj, const float* cam_pos, int V, int H, int W, const float* pts,
-                            const int32_t* index, const int32_t* n_dev, long long n, const float* query_cam,
-                            const float* normals, float* out_rgb, uint8_t* out_nviews, void* stream);
-int o2345_view_count_unlisted(const float* pts, long long n, const float* skip_if_positive, const float* maskvol, int D, const float* proj, int V,
-                              int H, int W, uint8_t* out, void* stream);
-
 // ---- stage entry points (used by the parity tests; the orchestrator below calls the same kernels) -----------------
+static int ray_coarse_launch(const float* rays_o, const float* rays_d, int R, float near, float far, const float* near_ray, const float* far_ray, int S,
+                             const float* t_rand, float* z, float* pts, const float* maskvol, int D, uint8_t* msk, void* stream) {
+    O2345_REQUIRE(rays_o && rays_d && z && pts && R > 0 && S > 1, "ray_coarse: bad arguments");
+    O2345_REQUIRE((near_ray != nullptr) == (far_ray != nullptr), "ray_coarse: per-ray near and far come together");
+    RayGeom g{rays_o, rays_d, R};
+    hipLaunchKernelGGL(k_ray_coarse, dim3(cdiv((long long)R * S, 256)), dim3(256), 0, (hipStream_t)stream, g, near, far, near_ray, far_ray, S, t_rand, z, pts,
+                       maskvol, D, msk);
+    return check_launch("ray_coarse");
+}
+
 int o2345_ray_coarse_jitter(const float* rays_o, const float* rays_d, int R, float near, float far, int S, const float* t_rand,
                             float* z, float* pts, void* stream) {
-    O2345_REQUIRE(rays_o && rays_d && z && pts && R > 0 && S > 1, "ray_coarse: bad arguments");
-    RayGeom g{rays_o, rays_d, R};
-    hipLaunchKernelGGL(k_ray_coarse, dim3(cdiv((long long)R * S, 256)), dim3(256), 0, (hipStream_t)stream, g, near, far, S, t_rand, z, pts);
-    return check_launch("ray_coarse");
+    return ray_coarse_launch(rays_o, rays_d, R, near, far, nullptr, nullptr, S, t_rand, z, pts, nullptr, 0, nullptr, stream);
+}
+
+int o2345_ray_coarse_per_ray(const float* rays_o, const float* rays_d, int R, const float* near_ray, const float* far_ray, int S,
+                             const float* t_rand, float* z, float* pts, void* stream) {
+    O2345_REQUIRE(near_ray && far_ray, "ray_coarse_per_ray: null pointer");
+    return ray_coarse_launch(rays_o, rays_d, R, 0.f, 0.f, near_ray, far_ray, S, t_rand, z, pts, nullptr, 0, nullptr, stream);
 }
 
 int o2345_ray_coarse(const float* rays_o, const float* rays_d, int R, float near, float far, int S, float* z, float* pts, void* stream) {
     return o2345_ray_coarse_jitter(rays_o, rays_d, R, near, far, S, nullptr, z, pts, stream);
 }
 
+// One launch of k_ray_round.  A merge of exactly NFIX samples runs fused (in LDS); any other block size is merged on the global lists first.
+static int ray_round_launch(int mode, RoundArgs a, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int R = a.g.R;
+    if (a.n_new > 0 && a.n_new != NFIX) {
+        hipLaunchKernelGGL(k_ray_merge_any, dim3(cdiv(R, 64)), dim3(64), 0, s, R, a.z, a.sdf, a.msk, a.S, a.new_z, a.new_sdf, a.new_msk, a.n_new);
+        a.S += a.n_new;
+        a.n_new = 0;
+        if (mode == RM_MERGE_ONLY) return check_launch("ray_merge");
+    }
+    const bool merge = a.n_new > 0;
+    const int rows = a.S + (merge ? NFIX : 0) + (mode == RM_UPSAMPLE ? a.n_imp : 0);
+    const size_t lds = (size_t)rows * RAY_LDS_ROW_BYTES;
+    O2345_REQUIRE(lds <= 160 * 1024, "ray kernels: %d list rows per ray do not fit the 160 KB of LDS (at most 284)", rows);
+    const dim3 grid(cdiv(R, RT)), block(RT);
+#define O2345_ROUND(M, MG)                                                        \
+    {                                                                             \
+        O2345_ENSURE_LDS((k_ray_round<M, MG>), 160 * 1024);                       \
+        hipLaunchKernelGGL((k_ray_round<M, MG>), grid, block, lds, s, a);         \
+    }
+    if (mode == RM_UPSAMPLE) { if (merge) O2345_ROUND(RM_UPSAMPLE, true) else O2345_ROUND(RM_UPSAMPLE, false) }
+    else if (mode == RM_FINALIZE) { if (merge) O2345_ROUND(RM_FINALIZE, true) else O2345_ROUND(RM_FINALIZE, false) }
+    else if (merge) O2345_ROUND(RM_MERGE_ONLY, true)
+#undef O2345_ROUND
+    return check_launch("ray_round");
+}
+
+// ---- stage entry points (used by the parity tests; the orchestrator below launches the same kernel with the merge fused in) -----------------
 int o2345_ray_upsample(const float* rays_o, const float* rays_d, int R, const float* z, const float* sdf, int S, float inv_s,
-                       const float* maskvol, int D, float* wbuf, int n_imp, float* new_z, float* new_pts, float* new_sdf,
+                       const float* maskvol, int D, int n_imp, float* new_z, float* new_pts, float* new_sdf,
                        int32_t* list, int32_t* count_dev, void* stream) {
-    O2345_REQUIRE(rays_o && rays_d && z && sdf && maskvol && wbuf && new_z && new_pts && new_sdf && list && count_dev, "ray_upsample: null pointer");
-    O2345_REQUIRE(n_imp >= 1 && n_imp <= 256, "ray_upsample: 1..256 new samples per call (got %d)", n_imp);
-    RayGeom g{rays_o, rays_d, R};
+    O2345_REQUIRE(rays_o && rays_d && z && sdf && maskvol && new_z && new_pts && new_sdf && list && count_dev, "ray_upsample: null pointer");
+    O2345_REQUIRE(n_imp >= 1 && n_imp <= 256 && S >= 2 && R > 0, "ray_upsample: 1..256 new samples per call, at least 2 samples per ray (got %d, %d)", n_imp, S);
     hipStream_t s = (hipStream_t)stream;
     O2345_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_ray_upsample, dim3(cdiv(R, 256)), dim3(256), 0, s, g, z, sdf, S, inv_s, maskvol, D, wbuf, n_imp, new_z, new_pts, new_sdf, list, count_dev);
+    RoundArgs a{};
+    a.g = RayGeom{rays_o, rays_d, R};
+    a.z = const_cast<float*>(z); a.sdf = const_cast<float*>(sdf); a.S = S;          // read-only without a merge
+    a.maskvol = maskvol; a.D = D; a.inv_s = inv_s; a.n_imp = n_imp;
+    a.out_z = new_z; a.out_pts = new_pts; a.out_sdf = new_sdf; a.list = list; a.count = count_dev;
+    int rc = ray_round_launch(RM_UPSAMPLE, a, stream);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_quirk_min2, dim3(1), dim3(1), 0, s, count_dev);
     return check_launch("ray_upsample");
 }
 
 int o2345_ray_merge(int R, float* z, float* sdf, int S, float* new_z, float* new_sdf, int n_new, void* stream) {
-    O2345_REQUIRE(z && sdf && new_z && new_sdf, "ray_merge: null pointer");
-    hipLaunchKernelGGL(k_ray_merge, dim3(cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, R, z, sdf, S, new_z, new_sdf, n_new);
-    return check_launch("ray_merge");
-}
-
-static int ray_finalize_launch(const float* rays_o, const float* rays_d, int R, const float* z, int S, float sample_dist,
-                               const float* maskvol, int D, float* mid_z, float* dists, float* pts, float* pm, float* sdf,
-                               float* grad, float* rgb, int32_t* list, int32_t* count_dev, void* stream, int defaults_everywhere) {
-    O2345_REQUIRE(rays_o && rays_d && z && maskvol && mid_z && dists && pts && pm && sdf && grad && rgb && list && count_dev, "ray_finalize: null pointer");
-    O2345_REQUIRE(S >= 1 && S <= 256, "ray_finalize: at most 256 samples per ray (got %d)", S);
-    RayGeom g{rays_o, rays_d, R};
-    hipStream_t s = (hipStream_t)stream;
-    O2345_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_ray_finalize, dim3(cdiv(R, 256)), dim3(256), 0, s, g, z, S, sample_dist, maskvol, D, mid_z, dists, pts, pm, sdf, grad, rgb, list, count_dev,
-                       defaults_everywhere);
-    return check_launch("ray_finalize");
+    O2345_REQUIRE(z && sdf && new_z && new_sdf && R > 0 && S >= 1 && n_new >= 1, "ray_merge: bad arguments");
+    RoundArgs a{};
+    a.g = RayGeom{nullptr, nullptr, R};
+    a.z = z; a.sdf = sdf; a.S = S; a.new_z = new_z; a.new_sdf = new_sdf; a.n_new = n_new;
+    return ray_round_launch(RM_MERGE_ONLY, a, stream);
 }
 
 int o2345_ray_finalize(const float* rays_o, const float* rays_d, int R, const float* z, int S, float sample_dist,
                        const float* maskvol, int D, float* mid_z, float* dists, float* pts, float* pm, float* sdf,
                        float* grad, float* rgb, int32_t* list, int32_t* count_dev, void* stream) {
-    return ray_finalize_launch(rays_o, rays_d, R, z, S, sample_dist, maskvol, D, mid_z, dists, pts, pm, sdf, grad, rgb, list, count_dev, stream, 1);
+    O2345_REQUIRE(rays_o && rays_d && z && maskvol && mid_z && dists && pts && pm && sdf && grad && rgb && list && count_dev, "ray_finalize: null pointer");
+    O2345_REQUIRE(S >= 1 && S <= 256 && R > 0, "ray_finalize: at most 256 samples per ray (got %d)", S);
+    O2345_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), (hipStream_t)stream));
+    RoundArgs a{};
+    a.g = RayGeom{rays_o, rays_d, R};
+    a.z = const_cast<float*>(z); a.sdf = const_cast<float*>(z); a.S = S;            // the SDF list is not used by the finalize step (staged, never read)
+    a.maskvol = maskvol; a.D = D; a.sample_dist = sample_dist;
+    a.mid_z = mid_z; a.dists = dists; a.pts = pts; a.pm = pm; a.o_sdf = sdf; a.grad = grad; a.rgb = rgb; a.defaults_everywhere = 1;
+    a.list = list; a.count = count_dev;
+    return ray_round_launch(RM_FINALIZE, a, stream);
 }
 
 int o2345_ray_composite(const float* rays_o, const float* rays_d, int R, int S, const float* mid_z, const float* dists,
@@ -229,106 +435,108 @@ int o2345_ray_composite(const float* rays_o, const float* rays_d, int R, int S, 
                   weights_sum && weights_max && depth_var && alpha_sum && grad_err && color_mask, "ray_composite: null pointer");
     RayGeom g{rays_o, rays_d, R};
     CompositeOut o{color, depth, weights, cdf, weights_sum, weights_max, depth_var, alpha_sum, grad_err, color_mask};
-    hipLaunchKernelGGL(k_ray_composite, dim3(cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, g, S, mid_z, dists, pm, sdf, grad, rgb, nviews, inv_s, alpha_inter_ratio, background, o);
+    hipLaunchKernelGGL(k_ray_composite, dim3(cdiv(R, 64)), dim3(64), 0, (hipStream_t)stream, g, S, mid_z, dists, pm, sdf, grad, rgb, nviews, inv_s, alpha_inter_ratio, background, o);
     return check_launch("ray_composite");
 }
 
 // ---- the whole render() call -----------------------------------------------------------------------------------------
-// Workspace layout (floats unless noted), S = n_samples + n_importance, R rays:
-//   z[S*R] sdf[S*R] wbuf[S*R] new_z[NI*R] new_sdf[NI*R] pts[3*S*R] list[S*R ints] count[16 ints]
-//   ... sorted list[S*R ints] + the workspace of o2345_list_sort_by_visibility for up to 32 views (csrc/list_sort.hip)
-size_t o2345_list_sort_workspace_bytes(long long n_max, int V);
-int o2345_list_sort_by_visibility(const float* pts, const int32_t* list, const int32_t* count_dev, long long n_max, const float* proj, int V, int H, int W,
-                                  int32_t* list_out, uint32_t* keys_out, void* workspace, size_t workspace_bytes, void* stream);
+// Workspace layout (floats unless noted), S = n_samples + n_importance, NI = n_importance / 4, R rays:
+//   z[S*R] sdf[S*R] new_z[NI*R] new_sdf[NI*R] pts[3*S*R] list[S*R ints] count[16 ints] msk[S*R bytes] new_msk[NI*R bytes]
+//   ... and, when the list is sorted: sorted list[S*R ints] + the workspace of o2345_list_sort_by_visibility (csrc/list_sort.hip)
 static size_t render_core_workspace_bytes(int R, int n_samples, int n_importance) {
     const size_t S = (size_t)n_samples + n_importance, NI = (size_t)(n_importance / 4 > 0 ? n_importance / 4 : 1);
-    return ((S * 3 + NI * 2 + 3 * S + S) * (size_t)R + 64) * 4;
+    const size_t bytes = ((S * 2 + NI * 2 + 3 * S + S) * (size_t)R + 64) * 4 + (S + NI) * (size_t)R;
+    return (bytes + 255) / 256 * 256;
 }
-size_t o2345_render_workspace_bytes(int R, int n_samples, int n_importance) {
+// The occupied-point list is grouped by view-visibility signature only where that pays: the sort is 4 launches per 8 views and costs 0.1 - 0.25 ms
+// whatever the list length, the colour kernel gains ~10 % of its time.  Below 2^20 sample slots (a 512-ray chunk of the reference's val loop has
+// 65,536: colour kernel 0.5 ms) the emission order is kept.  O2345_LIST_SORT=0 disables the sort everywhere (A/B knob).
+static bool render_sorts_list(int R, int n_samples, int n_importance, int V) {
+    return knobs().list_sort && V <= 32 && ((long long)n_samples + n_importance) * (long long)R >= (1ll << 20);
+}
+size_t o2345_render_workspace_bytes(int R, int n_samples, int n_importance, int V) {
     const size_t S = (size_t)n_samples + n_importance;
-    return render_core_workspace_bytes(R, n_samples, n_importance) + S * (size_t)R * 4 + o2345_list_sort_workspace_bytes((long long)(S * (size_t)R), 32);
+    size_t b = render_core_workspace_bytes(R, n_samples, n_importance);
+    if (render_sorts_list(R, n_samples, n_importance, V)) b += S * (size_t)R * 4 + o2345_list_sort_workspace_bytes((long long)(S * (size_t)R), V);
+    return b;
 }
-
-struct O2345RenderIO {
-    // scene
-    const float* sdf_blob; const float* color_blob; const float* vol_cl; const float* maskvol; int D;
-    const float* cmaps; const float* proj; const float* cam_pos; int V, H, W;
-    // rays
-    const float* rays_o; const float* rays_d; int R; float near, far; int n_samples, n_importance;
-    float inv_s, alpha_inter_ratio, background; const float* query_cam;
-    // outputs: per-sample arrays are sample-major [S][R] (+[,3])
-    float* mid_z; float* dists; float* pm; float* sdf; float* grad; float* rgb; uint8_t* nviews;
-    float* color; float* depth; float* weights; float* cdf; float* weights_sum; float* weights_max; float* depth_var;
-    float* alpha_sum; float* grad_err; uint8_t* color_mask; float* z_vals;
-    const float* color_mfma_blob;
-    int sdf_bf16;               // SDF network mode: 0 fp32 MFMA, 2 split-f16 (sdf_mlp_x3.hip).  (1 was the bf16 mode removed in round 3; the field keeps its name: ABI)
-    const float* color_x3_blob; // optional: split-f16 colour kernel
-    const float* t_rand;        // optional [R][n_samples]: stratified jitter of the coarse samples (perturb > 0)
-};
 
 int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace_bytes, void* stream) {
     O2345_REQUIRE(io && workspace, "render_rays: null pointer");
     const int R = io->R, NS = io->n_samples, NIMP = io->n_importance;
     O2345_REQUIRE(NIMP % 4 == 0 && NIMP > 0 && NS > 1, "render_rays: n_importance must be a positive multiple of 4");
-    O2345_REQUIRE(workspace_bytes >= o2345_render_workspace_bytes(R, NS, NIMP), "render_rays: workspace too small");
     O2345_REQUIRE(R > 0 && ((long long)NS + NIMP) * (long long)R < 2147483647LL, "render_rays: R * (n_samples + n_importance) must stay below 2^31 "
                   "(sample slots are 32-bit); split the ray batch (got R = %d)", R);
+    O2345_REQUIRE(workspace_bytes >= o2345_render_workspace_bytes(R, NS, NIMP, io->V), "render_rays: workspace too small");
+    O2345_REQUIRE(io->color_x3_blob || io->color_mfma_blob, "render_rays: a colour network blob is required (color_x3_blob or color_mfma_blob)");
+    O2345_REQUIRE((io->near_ray != nullptr) == (io->far_ray != nullptr), "render_rays: per-ray near and far come together");
     const size_t S = (size_t)NS + NIMP, NI = NIMP / 4, RR = R;
+    O2345_REQUIRE(S <= 256, "render_rays: at most 256 samples per ray (got %d)", (int)S);
     float* z = (float*)workspace;
     float* sdf = z + S * RR;
-    float* wbuf = sdf + S * RR;
-    float* new_z = wbuf + S * RR;
+    float* new_z = sdf + S * RR;
     float* new_sdf = new_z + NI * RR;
     float* pts = new_sdf + NI * RR;
     int* list = (int*)(pts + 3 * S * RR);
-    int* count = list + S * RR;
+    int* count = list + S * RR;                  // [0..3]: new points of the four up-sampling rounds, [4]: occupied mid-points
+    uint8_t* msk = (uint8_t*)(count + 64);       // occupancy of every sample point, carried with the lists
+    uint8_t* new_msk = msk + S * RR;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    O2345_REQUIRE(io->sdf_bf16 == 0 || io->sdf_bf16 == 2, "render_rays: SDF mode %d (0 = fp32, 2 = split-f16; the bf16 mode was removed)", io->sdf_bf16);
+    O2345_REQUIRE(io->sdf_mode == 0 || io->sdf_mode == 2, "render_rays: SDF mode %d (0 = fp32, 2 = split-f16; the bf16 mode 1 was removed)", io->sdf_mode);
     auto sdf_eval = [&](int variant, const float* p, const int* idx, const int* cnt, long long n, float* out, float* grad) {
-        if (io->sdf_bf16 == 2 && variant == 0) return o2345_sdf_mlp_x3(io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, stream);
-        if (io->sdf_bf16 == 2 && variant == 2) return o2345_sdf_grad_x3(io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, grad, stream);
+        if (io->sdf_mode == 2 && variant == 0) return o2345_sdf_mlp_x3(io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, stream);
+        if (io->sdf_mode == 2 && variant == 2) return o2345_sdf_grad_x3(io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, grad, stream);
         return o2345_sdf_mlp(variant, io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, nullptr, nullptr, grad, stream);
     };
-    if ((rc = o2345_ray_coarse_jitter(io->rays_o, io->rays_d, R, io->near, io->far, NS, io->t_rand, z, pts, stream))) return rc;
+    O2345_HIP(hipMemsetAsync(count, 0, 16 * sizeof(int), s));          // every device-side counter of the call, once
+    if ((rc = ray_coarse_launch(io->rays_o, io->rays_d, R, io->near, io->far, io->near_ray, io->far_ray, NS, io->t_rand, z, pts, io->maskvol, io->D, msk, stream))) return rc;
     // coarse SDF on ALL points (not masked, :525-528)
     if ((rc = sdf_eval(0, pts, nullptr, nullptr, (long long)NS * R, sdf, nullptr))) return rc;
+    // four up-sampling rounds (:531-547); round i > 0 first merges round i - 1's samples (cat_z_vals) inside the same kernel
+    RoundArgs ra{};
+    ra.g = RayGeom{io->rays_o, io->rays_d, R};
+    ra.z = z; ra.sdf = sdf; ra.msk = msk; ra.maskvol = io->maskvol; ra.D = io->D;
+    ra.new_z = new_z; ra.new_sdf = new_sdf; ra.new_msk = new_msk;
+    ra.n_imp = (int)NI; ra.out_z = new_z; ra.out_pts = pts; ra.out_sdf = new_sdf; ra.out_msk = new_msk; ra.list = list;
     int cur = NS;
     for (int i = 0; i < 4; ++i) {
-        if ((rc = o2345_ray_upsample(io->rays_o, io->rays_d, R, z, sdf, cur, 64.f * (float)(1 << i), io->maskvol, io->D, wbuf, (int)NI, new_z, pts, new_sdf, list, count, stream))) return rc;
-        if ((rc = sdf_eval(0, pts, list, count, 0, new_sdf, nullptr))) return rc;
-        if ((rc = o2345_ray_merge(R, z, sdf, cur, new_z, new_sdf, (int)NI, stream))) return rc;
-        cur += (int)NI;
+        ra.S = cur; ra.n_new = i ? (int)NI : 0; ra.inv_s = 64.f * (float)(1 << i); ra.count = count + i;
+        if ((rc = ray_round_launch(RM_UPSAMPLE, ra, stream))) return rc;
+        cur += ra.n_new;
+        hipLaunchKernelGGL(k_quirk_min2, dim3(1), dim3(1), 0, s, count + i);
+        if ((rc = sdf_eval(0, pts, list, count + i, 0, new_sdf, nullptr))) return rc;
     }
-    const float sample_dist = (io->far - io->near) / (float)NS;
+    count += 4;
+    // :484 -- the caller passes the mean over the rays for per-ray near / far; the scalar form is (far - near) / n_samples
+    const float sample_dist = io->sample_dist > 0.f ? io->sample_dist : (io->far - io->near) / (float)NS;
     float* fpts = pts;   // reuse
-    if ((rc = ray_finalize_launch(io->rays_o, io->rays_d, R, z, (int)S, sample_dist, io->maskvol, io->D, io->mid_z, io->dists, fpts, io->pm, io->sdf, io->grad, io->rgb, list, count, stream, 0))) return rc;
+    // the last cat_z_vals fused with render_core's head
+    ra.S = cur; ra.n_new = (int)NI; ra.count = count; ra.sample_dist = sample_dist;
+    ra.mid_z = io->mid_z; ra.dists = io->dists; ra.pts = fpts; ra.pm = io->pm; ra.o_sdf = io->sdf; ra.grad = io->grad; ra.rgb = io->rgb; ra.defaults_everywhere = 0;
+    if ((rc = ray_round_launch(RM_FINALIZE, ra, stream))) return rc;
     hipLaunchKernelGGL(k_quirk_first100, dim3(1), dim3(128), 0, s, count, list, R, (int)S);
     // the list grouped by view-visibility signature (stable): the colour kernel then skips every (tile, view) pair in which no point sees the view instead of
-    // 3/4 of them -- 40.0 -> 36.1 ms at 8 views, bit-identical results (csrc/list_sort.hip).  O2345_LIST_SORT=0: the emission order (A/B knob)
-    {
-        const char* e = getenv("O2345_LIST_SORT");
-        if (!(e && e[0] == '0') && io->V <= 32) {
-            int* slist = (int*)((char*)workspace + render_core_workspace_bytes(R, NS, NIMP));
-            void* sort_ws = (void*)(slist + S * RR);
-            if ((rc = o2345_list_sort_by_visibility(fpts, list, count, (long long)(S * RR), io->proj, io->V, io->H, io->W, slist, nullptr, sort_ws,
-                                                    o2345_list_sort_workspace_bytes((long long)(S * RR), 32), stream))) return rc;
-            list = slist;
-        }
+    // 3/4 of them -- 40.0 -> 36.1 ms at 8 views, bit-identical results (csrc/list_sort.hip); only for lists long enough to pay for it (render_sorts_list)
+    if (render_sorts_list(R, NS, NIMP, io->V)) {
+        int* slist = (int*)((char*)workspace + render_core_workspace_bytes(R, NS, NIMP));
+        void* sort_ws = (void*)(slist + S * RR);
+        if ((rc = o2345_list_sort_by_visibility(fpts, list, count, (long long)(S * RR), io->proj, io->V, io->H, io->W, slist, nullptr, sort_ws,
+                                                o2345_list_sort_workspace_bytes((long long)(S * RR), io->V), stream))) return rc;
+        list = slist;
     }
     if ((rc = sdf_eval(2, fpts, list, count, 0, io->sdf, io->grad))) return rc;
     // valid-view counts (feed the per-ray colour mask): the colour kernels write them for the points they evaluate (the occupied ones, 88 % at
     // BASELINE config 2); this pass covers the rest (four IEEE divisions per view make it VALU-bound: 0.48 ms over all points)
     if ((rc = o2345_view_count_unlisted(fpts, (long long)S * R, io->pm, io->maskvol, io->D, io->proj, io->V, io->H, io->W, io->nviews, stream))) return rc;
     if (io->color_x3_blob)
-        rc = o2345_color_points_x3(io->color_x3_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, io->nviews, stream);
-    else if (io->color_mfma_blob)
-        rc = o2345_color_points_mfma(io->color_mfma_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, io->nviews, stream);
+        rc = o2345_color_points_x3(io->color_x3_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, io->nviews, io->color_stats, stream);
     else
-        rc = o2345_color_points(io->color_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, io->nviews, stream);
+        rc = o2345_color_points_mfma(io->color_mfma_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, io->nviews, io->color_stats, stream);
     if (rc) return rc;
     if ((rc = o2345_ray_composite(io->rays_o, io->rays_d, R, (int)S, io->mid_z, io->dists, io->pm, io->sdf, io->grad, io->rgb, io->nviews, io->inv_s, io->alpha_inter_ratio, io->background,
                                   io->color, io->depth, io->weights, io->cdf, io->weights_sum, io->weights_max, io->depth_var, io->alpha_sum, io->grad_err, io->color_mask, stream))) return rc;
+    if (io->scalars) hipLaunchKernelGGL(k_ray_scalars, dim3(1), dim3(1024), 0, s, R, (int)S, io->alpha_sum, io->grad_err, count, io->scalars);
     if (io->z_vals) O2345_HIP(hipMemcpyAsync(io->z_vals, z, S * RR * sizeof(float), hipMemcpyDeviceToDevice, s));
     return check_launch("render_rays");
 }

@@ -33,21 +33,36 @@ O2345_HD float mask_at(const float* __restrict__ maskvol, int D, float x, float 
     return v < 0 ? 0.f : maskvol[v];
 }
 
-// up_sample + sample_pdf(det=True): from S sorted samples (z, sdf) of ray r produce n_imp new z values.
-// wbuf: scratch [>= S-1][R].  Outputs new_z[t*R + r], t < n_imp.
-O2345_HD void upsample_ray(const RayGeom& g, int r, const float* __restrict__ z, const float* __restrict__ sdf, int S,
-                           float inv_s, const float* __restrict__ maskvol, int D, float* __restrict__ wbuf,
-                           int n_imp, float* __restrict__ new_z) {
-    const int R = g.R;
-    float px, py, pz;
-    float z0 = z[r], s0 = sdf[r];
-    ray_point(g, r, z0, px, py, pz);
-    float m0 = mask_at(maskvol, D, px, py, pz);
+// ---- per-ray list accessors ----------------------------------------------------------------------------------------------------------------
+// The sampler math below is written ONCE, against an accessor: rows of ONE ray's sorted lists (depth z, SDF, point-inside-mask flag), a scratch
+// row for the section weights, and a sink for the new depths.  Two accessors exist: GlobalRay (the sample-major global arrays, a[s * R + r]: the
+// host-check build and the definition of the semantics) and LdsRay (csrc/render.hip: the lists of 64 rays staged in LDS, a[s * 64 + lane]: every
+// access of the serial per-ray chains costs an LDS round trip instead of a dependent trip to L2 / HBM).
+struct GlobalRay {
+    RayGeom g; int r; size_t R;
+    const float* z_; const float* sdf_; float* w_; float* out_;
+    const float* maskvol; int D;
+    O2345_HD float z(int s) const { return z_[(size_t)s * R + r]; }
+    O2345_HD float sdf(int s) const { return sdf_[(size_t)s * R + r]; }
+    O2345_HD float msk(int s, float zs) const {            // occupancy of the sample point (nearest voxel of the mask volume)
+        float x, y, w;
+        ray_point(g, r, zs, x, y, w);
+        return mask_at(maskvol, D, x, y, w);
+    }
+    O2345_HD void set_w(int s, float v) { w_[(size_t)s * R + r] = v; }
+    O2345_HD float w(int s) const { return w_[(size_t)s * R + r]; }
+    O2345_HD void out(int t, float v) { out_[(size_t)t * R + r] = v; }
+};
+
+// up_sample + sample_pdf(det=True): from S sorted samples (z, sdf) of one ray produce n_imp new z values (a.out(t, z_new), t < n_imp).
+template <class A>
+O2345_HD void upsample_core(A& a, int S, float inv_s, int n_imp) {
+    float z0 = a.z(0), s0 = a.sdf(0);
+    float m0 = a.msk(0, z0);
     float prev_dot = 0.f, T = 1.f, wsum = 0.f;
     for (int s = 0; s + 1 < S; ++s) {
-        const float z1 = z[(size_t)(s + 1) * R + r], s1 = sdf[(size_t)(s + 1) * R + r];
-        ray_point(g, r, z1, px, py, pz);
-        const float m1 = mask_at(maskvol, D, px, py, pz);
+        const float z1 = a.z(s + 1), s1 = a.sdf(s + 1);
+        const float m1 = a.msk(s + 1, z1);
         const float pm = m0 * m1;
         const float mid = (s0 + s1) * 0.5f;
         const float dot_raw = (s1 - s0) / (z1 - z0 + 1e-5f);
@@ -60,7 +75,7 @@ O2345_HD void upsample_ray(const RayGeom& g, int r, const float* __restrict__ z,
         const float alpha = pm * ((pc - nc + 1e-5f) / (pc + 1e-5f));
         const float w = alpha * T + 1e-5f;            // sample_pdf: weights + 1e-5
         T = T * (1.f - alpha + 1e-7f);
-        wbuf[(size_t)s * R + r] = w;
+        a.set_w(s, w);
         wsum += w;
         z0 = z1; s0 = s1; m0 = m1;
     }
@@ -73,7 +88,7 @@ O2345_HD void upsample_ray(const RayGeom& g, int r, const float* __restrict__ z,
         while (k < S && !(c_hi > u)) {
             ++k;
             c_lo = c_hi;
-            if (k < S) c_hi = c_hi + wbuf[(size_t)(k - 1) * R + r] / wsum;
+            if (k < S) c_hi = c_hi + a.w(k - 1) / wsum;
         }
         // ind = k (may be S).  below = max(0, ind-1), above = min(S-1, ind)
         int below = k - 1 < 0 ? 0 : k - 1, above = k > S - 1 ? S - 1 : k;
@@ -82,40 +97,96 @@ O2345_HD void upsample_ray(const RayGeom& g, int r, const float* __restrict__ z,
         float den = ca - cb;
         if (den < 1e-5f) den = 1.f;
         const float tt = (u - cb) / den;
-        const float zb = z[(size_t)below * R + r], za = z[(size_t)above * R + r];
-        new_z[(size_t)t * R + r] = zb + tt * (za - zb);
+        const float zb = a.z(below), za = a.z(above);
+        a.out(t, zb + tt * (za - zb));
     }
 }
 
-// cat_z_vals: merge n_new samples (new_z/new_sdf [n_new][R]) into the sorted list (z/sdf [S][R]) in place
-// (capacity S + n_new).  Equal keys keep existing samples first.
+// wbuf: scratch [>= S-1][R].  Outputs new_z[t*R + r], t < n_imp.
+O2345_HD void upsample_ray(const RayGeom& g, int r, const float* __restrict__ z, const float* __restrict__ sdf, int S,
+                           float inv_s, const float* __restrict__ maskvol, int D, float* __restrict__ wbuf,
+                           int n_imp, float* __restrict__ new_z) {
+    GlobalRay a{g, r, (size_t)g.R, z, sdf, wbuf, new_z, maskvol, D};
+    upsample_core(a, S, inv_s, n_imp);
+}
+
+// cat_z_vals: merge n_new samples into the sorted list of S samples (capacity S + n_new): a stable merge in which, among equal depths, existing
+// samples stay in front of new ones.  Written as a RANK merge so that no step depends on the previous one (the lists may live in LDS or registers):
+//   existing sample i moves to i + #{new j : z_new[j] < z[i]},   new sample j (after sorting the new block) goes to j + #{i : z[i] <= z_new[j]}.
+// Moving the existing samples in DESCENDING i makes the move in-place safe (the target slot i + c >= i has been vacated already).
+// Accessor: z(i) / sdf(i) / tag(i) read, put(i, z, sdf, tag) write of the merged list; nz / ns / nt: the new block (any order), sorted here.
+template <class A, int NMAX>
+O2345_HD void merge_core(A& a, int S, float (&nz)[NMAX], float (&ns)[NMAX], unsigned (&nt)[NMAX], int n_new) {
+    // insertion sort of the new block (ascending in practice: the inverse CDF of ascending u)
+    for (int i = 1; i < n_new; ++i) {
+        const float kz = nz[i], ks = ns[i];
+        const unsigned kt = nt[i];
+        int b = i - 1;
+        while (b >= 0 && nz[b] > kz) { nz[b + 1] = nz[b]; ns[b + 1] = ns[b]; nt[b + 1] = nt[b]; --b; }
+        nz[b + 1] = kz; ns[b + 1] = ks; nt[b + 1] = kt;
+    }
+    int cnt[NMAX];
+    for (int j = 0; j < n_new; ++j) cnt[j] = 0;
+    for (int i = S - 1; i >= 0; --i) {
+        const float zi = a.z(i);
+        int c = 0;
+        for (int j = 0; j < n_new; ++j) { c += nz[j] < zi ? 1 : 0; cnt[j] += zi <= nz[j] ? 1 : 0; }
+        if (c) a.put(i + c, zi, a.sdf(i), a.tag(i));
+    }
+    for (int j = 0; j < n_new; ++j) a.put(j + cnt[j], nz[j], ns[j], nt[j]);
+}
+
+// The same merge for a new block of EXACTLY N samples held in registers (device path, N = n_importance / 4 = 16): every index into the block is a
+// compile-time constant (no scratch memory), the block is sorted by an odd-even transposition network (skipped when already ascending).
+template <class A, int N>
+O2345_HD void merge_core_fixed(A& a, int S, float (&nz)[N], float (&ns)[N], unsigned (&nt)[N], bool block_is_sorted) {
+    if (!block_is_sorted) {
+#pragma unroll
+        for (int round = 0; round < N; ++round) {
+#pragma unroll
+            for (int i = round & 1; i + 1 < N; i += 2) {
+                const bool sw = nz[i] > nz[i + 1];                     // strict: equal depths keep their order
+                const float z0 = sw ? nz[i + 1] : nz[i], z1 = sw ? nz[i] : nz[i + 1];
+                const float s0 = sw ? ns[i + 1] : ns[i], s1 = sw ? ns[i] : ns[i + 1];
+                const unsigned t0 = sw ? nt[i + 1] : nt[i], t1 = sw ? nt[i] : nt[i + 1];
+                nz[i] = z0; nz[i + 1] = z1; ns[i] = s0; ns[i + 1] = s1; nt[i] = t0; nt[i + 1] = t1;
+            }
+        }
+    }
+    int cnt[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) cnt[j] = 0;
+    for (int i = S - 1; i >= 0; --i) {
+        const float zi = a.z(i);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { c += nz[j] < zi ? 1 : 0; cnt[j] += zi <= nz[j] ? 1 : 0; }
+        if (c) a.put(i + c, zi, a.sdf(i), a.tag(i));
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) a.put(j + cnt[j], nz[j], ns[j], nt[j]);
+}
+
+// cat_z_vals on the global sample-major arrays: merge n_new samples (new_z/new_sdf [n_new][R]) into the sorted list (z/sdf [S][R]) in place
+// (capacity S + n_new).  Equal keys keep existing samples first.  (The new block is also left sorted in new_z / new_sdf, as before.)
+struct GlobalMerge {
+    float* z_; float* sdf_; size_t R; int r;
+    O2345_HD float z(int i) const { return z_[(size_t)i * R + r]; }
+    O2345_HD float sdf(int i) const { return sdf_[(size_t)i * R + r]; }
+    O2345_HD unsigned tag(int) const { return 0u; }
+    O2345_HD void put(int i, float zv, float sv, unsigned) { z_[(size_t)i * R + r] = zv; sdf_[(size_t)i * R + r] = sv; }
+};
 O2345_HD void merge_ray(int r, int R, float* __restrict__ z, float* __restrict__ sdf, int S, float* __restrict__ new_z,
                         float* __restrict__ new_sdf, int n_new) {
-    // insertion sort of the new block (already ascending in practice)
-    for (int a = 1; a < n_new; ++a) {
-        const float kz = new_z[(size_t)a * R + r], ks = new_sdf[(size_t)a * R + r];
-        int b = a - 1;
-        while (b >= 0 && new_z[(size_t)b * R + r] > kz) {
-            new_z[(size_t)(b + 1) * R + r] = new_z[(size_t)b * R + r];
-            new_sdf[(size_t)(b + 1) * R + r] = new_sdf[(size_t)b * R + r];
-            --b;
-        }
-        new_z[(size_t)(b + 1) * R + r] = kz;
-        new_sdf[(size_t)(b + 1) * R + r] = ks;
-    }
-    int i = S - 1, j = n_new - 1, o = S + n_new - 1;
-    while (j >= 0) {
-        const float zn = new_z[(size_t)j * R + r];
-        if (i >= 0 && z[(size_t)i * R + r] > zn) {
-            z[(size_t)o * R + r] = z[(size_t)i * R + r];
-            sdf[(size_t)o * R + r] = sdf[(size_t)i * R + r];
-            --i;
-        } else {
-            z[(size_t)o * R + r] = zn;
-            sdf[(size_t)o * R + r] = new_sdf[(size_t)j * R + r];
-            --j;
-        }
-        --o;
+    constexpr int NMAX = 64;
+    float nz[NMAX], ns[NMAX];
+    unsigned nt[NMAX];
+    for (int base = 0; base < n_new; base += NMAX) {                 // blocks of at most NMAX new samples (the renderer uses 16)
+        const int nb = n_new - base < NMAX ? n_new - base : NMAX;
+        for (int j = 0; j < nb; ++j) { nz[j] = new_z[(size_t)(base + j) * R + r]; ns[j] = new_sdf[(size_t)(base + j) * R + r]; nt[j] = 0u; }
+        GlobalMerge a{z, sdf, (size_t)R, r};
+        merge_core<GlobalMerge, NMAX>(a, S + base, nz, ns, nt, nb);
+        for (int j = 0; j < nb; ++j) { new_z[(size_t)(base + j) * R + r] = nz[j]; new_sdf[(size_t)(base + j) * R + r] = ns[j]; }
     }
 }
 
@@ -142,28 +213,48 @@ O2345_HD void composite_ray(const RayGeom& g, int r, int S, const float* __restr
     const float dx = g.rays_d[3 * r], dy = g.rays_d[3 * r + 1], dz = g.rays_d[3 * r + 2];
     float T = 1.f, wsum = 0.f, wmax = 0.f, asum = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, ge = 0.f, gm = 0.f;
     int n_seen = 0;
-    for (int s = 0; s < S; ++s) {
-        const size_t p = (size_t)s * R + r;
-        const float m = pm[p];
-        const float gx = grad[3 * p], gy = grad[3 * p + 1], gz = grad[3 * p + 2];
-        const float tdot = dx * gx + dy * gy + dz * gz;
-        float icos = -(fmaxf(-tdot * 0.5f + 0.5f, 0.f) * (1.f - alpha_inter_ratio) + fmaxf(-tdot, 0.f) * alpha_inter_ratio);
-        icos = icos * m;
-        const float half = fminf(fmaxf(icos, -10.f), 10.f) * dists[p] * 0.5f;
-        const float sv = sdf[p];
-        const float pc = sigmoidf_((sv - half) * inv_s), nc = sigmoidf_((sv + half) * inv_s);
-        float alpha = (pc - nc + 1e-5f) / (pc + 1e-5f);
-        alpha = fminf(fmaxf(alpha, 0.f), 1.f) * m;
-        const float w = alpha * T;
-        T = T * (1.f - alpha + 1e-7f);
-        o.weights[p] = w;
-        o.cdf[p] = pc;
-        wsum += w; wmax = fmaxf(wmax, w); asum += alpha;
-        c0 += rgb[3 * p] * w; c1 += rgb[3 * p + 1] * w; c2 += rgb[3 * p + 2] * w;
-        dep += mid_z[p] * w;
-        const float gn = sqrtf(gx * gx + gy * gy + gz * gz) - 1.f;
-        ge += m * (gn * gn); gm += m;
-        n_seen += nviews[p] >= 2 ? 1 : 0;
+    // The per-sample inputs do not depend on the running transmittance: a block of CB samples is LOADED first (11 values each, all loads of the
+    // block in flight together), then the serial chain runs over registers -- the arithmetic and its order are those of a plain loop over s.
+    constexpr int CB = 8;
+    float* __restrict__ wout = o.weights;
+    float* __restrict__ cout_ = o.cdf;
+    for (int sb = 0; sb < S; sb += CB) {
+        float bm[CB], bd[CB], bs[CB], bz[CB], bg[CB][3], bc[CB][3];
+        int bn[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            const int s = sb + k < S ? sb + k : S - 1;                 // the tail re-reads the last sample (never used)
+            const size_t p = (size_t)s * R + r;
+            bm[k] = pm[p]; bd[k] = dists[p]; bs[k] = sdf[p]; bz[k] = mid_z[p]; bn[k] = nviews[p];
+            bg[k][0] = grad[3 * p]; bg[k][1] = grad[3 * p + 1]; bg[k][2] = grad[3 * p + 2];
+            bc[k][0] = rgb[3 * p]; bc[k][1] = rgb[3 * p + 1]; bc[k][2] = rgb[3 * p + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            if (sb + k < S) {
+                const size_t p = (size_t)(sb + k) * R + r;
+                const float m = bm[k];
+                const float gx = bg[k][0], gy = bg[k][1], gz = bg[k][2];
+                const float tdot = dx * gx + dy * gy + dz * gz;
+                float icos = -(fmaxf(-tdot * 0.5f + 0.5f, 0.f) * (1.f - alpha_inter_ratio) + fmaxf(-tdot, 0.f) * alpha_inter_ratio);
+                icos = icos * m;
+                const float half = fminf(fmaxf(icos, -10.f), 10.f) * bd[k] * 0.5f;
+                const float sv = bs[k];
+                const float pc = sigmoidf_((sv - half) * inv_s), nc = sigmoidf_((sv + half) * inv_s);
+                float alpha = (pc - nc + 1e-5f) / (pc + 1e-5f);
+                alpha = fminf(fmaxf(alpha, 0.f), 1.f) * m;
+                const float w = alpha * T;
+                T = T * (1.f - alpha + 1e-7f);
+                wout[p] = w;
+                cout_[p] = pc;
+                wsum += w; wmax = fmaxf(wmax, w); asum += alpha;
+                c0 += bc[k][0] * w; c1 += bc[k][1] * w; c2 += bc[k][2] * w;
+                dep += bz[k] * w;
+                const float gn = sqrtf(gx * gx + gy * gy + gz * gz) - 1.f;
+                ge += m * (gn * gn); gm += m;
+                n_seen += bn[k] >= 2 ? 1 : 0;
+            }
+        }
     }
     const float bg = background * (1.f - wsum);
     o.color[3 * r] = c0 + bg; o.color[3 * r + 1] = c1 + bg; o.color[3 * r + 2] = c2 + bg;
@@ -172,10 +263,20 @@ O2345_HD void composite_ray(const RayGeom& g, int r, int S, const float* __restr
     o.grad_err[2 * r] = ge; o.grad_err[2 * r + 1] = gm;
     o.color_mask[r] = n_seen > 8 ? 1 : 0;
     float dv = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const size_t p = (size_t)s * R + r;
-        const float d = mid_z[p] - dep;
-        dv += d * d * o.weights[p];
+    for (int sb = 0; sb < S; sb += CB) {
+        float bz[CB], bw[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            const int s = sb + k < S ? sb + k : S - 1;
+            const size_t p = (size_t)s * R + r;
+            bz[k] = mid_z[p]; bw[k] = wout[p];
+        }
+#pragma unroll
+        for (int k = 0; k < CB; ++k)
+            if (sb + k < S) {
+                const float d = bz[k] - dep;
+                dv += d * d * bw[k];
+            }
     }
     o.depth_var[r] = dv;
 }

@@ -295,18 +295,16 @@ int o2345_sdf_mlp_ex(int variant, const float* blob, const float* vol_cl, int D,
     constexpr size_t N_A0 = 4 * ST0 * 64, N_A1 = 4 * ST1 * 64, N_A1T = 5 * STB * 64;
     size_t lds_floats = (variant == VAR_SDF ? N_A0 + N_A1 : variant == VAR_FULL ? 2 * N_A1 : N_A1 + N_A1T) + MISC_SIZE;
     size_t lds_bytes = lds_floats * sizeof(float);
-    hipError_t e;
     if (variant == VAR_SDF) {
-        e = hipFuncSetAttribute((const void*)k_sdf_mlp<VAR_SDF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        O2345_ENSURE_LDS(k_sdf_mlp<VAR_SDF>, lds_bytes);
         hipLaunchKernelGGL(k_sdf_mlp<VAR_SDF>, dim3(grid), dim3(threads), lds_bytes, s, a);
     } else if (variant == VAR_FULL) {
-        e = hipFuncSetAttribute((const void*)k_sdf_mlp<VAR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        O2345_ENSURE_LDS(k_sdf_mlp<VAR_FULL>, lds_bytes);
         hipLaunchKernelGGL(k_sdf_mlp<VAR_FULL>, dim3(grid), dim3(threads), lds_bytes, s, a);
     } else {
-        e = hipFuncSetAttribute((const void*)k_sdf_mlp<VAR_GRAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        O2345_ENSURE_LDS(k_sdf_mlp<VAR_GRAD>, lds_bytes);
         hipLaunchKernelGGL(k_sdf_mlp<VAR_GRAD>, dim3(grid), dim3(threads), lds_bytes, s, a);
     }
-    (void)e;
     return check_launch("sdf_mlp");
 }
 

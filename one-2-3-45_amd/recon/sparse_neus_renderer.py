@@ -9,17 +9,36 @@ from .rendering_network import DeferredColour
 from .sparse_sdf_network import channel_last
 
 
+def _attr_cache(t, name, key, make):
+    """A value derived from tensor ``t`` (and nothing that ``key`` does not capture), memoised ON the tensor object: valid while the same object has
+    the same version counter (any in-place write bumps it).  The trainer hands the SAME tensors to every 512-ray chunk of an image
+    (trainer_generic.py:365-416 slices the sample dict once, then loops), so per-image work is done once, not 128 times."""
+    hit = getattr(t, name, None)
+    k = (t._version,) + tuple(key)
+    if hit is not None and hit[0] == k:
+        return hit[1]
+    val = make()
+    try:
+        setattr(t, name, (k, val))
+    except Exception:                      # a tensor subclass without a __dict__: just do not cache
+        pass
+    return val
+
+
 def _scene_maps(feature_maps, color_maps, w2cs, intrinsics):
-    cm = getattr(feature_maps, "_o2345_cmaps", None)
-    if cm is None:
-        cm = ops.pack_color_maps(feature_maps.detach().contiguous().float(), color_maps.detach().contiguous().float())
-        try:
-            feature_maps._o2345_cmaps = cm
-        except Exception:
-            pass
-    proj = torch.matmul(intrinsics, w2cs[:, :3, :]).contiguous().float()
-    cam_pos = torch.inverse(w2cs)[:, :3, 3].contiguous().float()
+    """-> (colour map [V,H,W,64] = rgb | features | pad, proj [V,3,4], cam_pos [V,3]) of the scene's source views (models/projector.py:96-228 gathers from
+    them); cached per tensor object + version."""
+    cm = _attr_cache(feature_maps, "_o2345_cmaps", (id(color_maps), color_maps._version),
+                     lambda: ops.pack_color_maps(feature_maps.detach().contiguous().float(), color_maps.detach().contiguous().float()))
+    proj, cam_pos = _attr_cache(w2cs, "_o2345_cam", (id(intrinsics), intrinsics._version),
+                                lambda: ops.camera_terms(intrinsics.detach(), w2cs.detach()))
     return cm, proj, cam_pos
+
+
+def _host_scalar(t):
+    """float(t) for a one-element tensor, read back ONCE per (tensor object, version): near / far / the variance parameter are device tensors that the
+    trainer passes unchanged to every chunk; reading them per call is a device synchronisation per chunk."""
+    return _attr_cache(t, "_o2345_host", (), lambda: float(t.reshape(-1)[0]))
 
 
 class Projector:
@@ -117,36 +136,48 @@ class SparseNeuSRenderer(nn.Module):
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
         if pre_sample or bg_ratio > 0 or not if_general_rendering:
             raise NotImplementedError("o2345 render: general rendering without pre_sample / bg_ratio (the released val / export configuration)")
+        if rays_o.shape[0] == 0:
+            raise ValueError("o2345 render: empty ray batch")
         cm, proj, cam_pos = _scene_maps(feature_maps, color_maps, w2cs, intrinsics)
         R = rays_o.shape[0]
-        # stratified jitter exactly as the reference draws it (:506-515): torch.rand(z_vals.shape) on the HOST generator, then moved to
-        # the device -> the same numbers as the reference under the same torch.manual_seed; the kernel applies lower + (upper-lower)*t
-        t_rand = torch.rand(R, self.n_samples).to(rays_o.device) if perturb > 0 else None
-        scene = dict(sdf_blob=sdf_network.sdf_layer.blob(), color_blob=rendering_network.blob(), vol_cl=channel_last(conditional_volume),
-                     maskvol=conditional_valid_mask_volume.reshape(-1).contiguous().float(), cmaps=cm, proj=proj, cam_pos=cam_pos,
-                     color_mfma_blob=rendering_network.mfma_blob(),
-                     color_x3_blob=rendering_network.x3_blob())
-        inv_s = float(torch.exp(self.variance_network.variance.detach() * 10.0).clip(1e-6, 1e6))
-        nt, ft = torch.as_tensor(near).reshape(-1).float(), torch.as_tensor(far).reshape(-1).float()
-        if nt.numel() > 1 and (bool((nt != nt[0]).any()) or bool((ft != ft[0]).any())):
-            raise NotImplementedError("o2345 render: one near / far pair per call (the runner passes the query view's [1] tensors); "
-                                      "per-ray near / far are not supported")
-        nr, fr = float(nt[0]), float(ft[0])
+        dev = rays_o.device
+        # stratified jitter exactly as the reference draws it (:506-515): torch.rand(z_vals.shape) on the HOST generator, then moved to the device
+        # -> the same numbers as the reference under the same torch.manual_seed; drawn into pinned memory and copied asynchronously (torch's
+        # caching host allocator keeps the block until the copy has run), the kernel applies lower + (upper - lower) * t
+        t_rand = torch.rand(R, self.n_samples, pin_memory=dev.type == "cuda").to(dev, non_blocking=True) if perturb > 0 else None
+        scene = dict(sdf_blob=sdf_network.sdf_layer.blob(), vol_cl=channel_last(conditional_volume),
+                     maskvol=_attr_cache(conditional_valid_mask_volume, "_o2345_flat", (), lambda: conditional_valid_mask_volume.reshape(-1).contiguous().float()),
+                     cmaps=cm, proj=proj, cam_pos=cam_pos, color_mfma_blob=rendering_network.mfma_blob(), color_x3_blob=rendering_network.x3_blob())
+        var = self.variance_network.variance
+        inv_s = _attr_cache(var, "_o2345_inv_s", (), lambda: float(torch.exp(var.detach() * 10.0).clip(1e-6, 1e6)))
+        # near / far: one value each (the runner passes the query view's [1] tensors) or one per ray ([N_rays, 1], :486-490)
+        nt, ft = torch.as_tensor(near), torch.as_tensor(far)
+        sample_dist = None
+        if nt.numel() == 1 and ft.numel() == 1:
+            nr, fr = _host_scalar(nt), _host_scalar(ft)
+        else:
+            nr = nt.to(dev).float().reshape(-1).expand(R).contiguous() if nt.numel() in (1, R) else None
+            fr = ft.to(dev).float().reshape(-1).expand(R).contiguous() if ft.numel() in (1, R) else None
+            if nr is None or fr is None:
+                raise ValueError(f"o2345 render: near / far must have 1 or N_rays = {R} elements (got {nt.numel()}, {ft.numel()})")
+            sample_dist = float(((fr - nr) / self.n_samples).mean())                   # :484
         o = ops.render_rays(scene, rays_o.contiguous().float(), rays_d.contiguous().float(), nr, fr, self.n_samples, self.n_importance,
                             inv_s, float(alpha_inter_ratio), 0.0 if background_rgb is None else float(background_rgb),    # None: nothing is added (:430-431)
-                            query_c2w.reshape(-1, 4, 4)[0, :3, 3].contiguous().float(), t_rand=t_rand)
+                            _attr_cache(query_c2w, "_o2345_qcam", (), lambda: query_c2w.reshape(-1, 4, 4)[0, :3, 3].contiguous().float()),
+                            t_rand=t_rand, sample_dist=sample_dist, want_scalars=True)
         S = self.n_samples + self.n_importance
-        pm = o["pm"].t()
-        ge = o["grad_err"].sum(0)
-        pts_random = torch.rand([1024, 3], device=rays_o.device) * 2 - 1
-        sdf_random = sdf_network.sdf(pts_random, conditional_volume, lod=lod)["sdf_pts_scale%d" % lod]
-        color = o["color"]
-        return {"depth": o["depth"][:, None], "color_fine": color, "color_fine_mask": o["color_mask"].bool()[:, None], "color_outside": None,
-                "color_outside_mask": None, "color_mlp": None, "color_mlp_mask": None, "variance": torch.tensor(1.0 / inv_s, device=rays_o.device),
+        # the 1,024 random points of every call (:579-582): drawn on the device generator like the reference's torch.rand(...) * 2 - 1, evaluated by the
+        # SDF-only kernel (the reference's sdf() also returns 128 features nobody reads here)
+        pts_random = torch.empty(1024, 3, device=dev).uniform_(-1.0, 1.0)
+        sdf_random = ops.sdf_mlp(scene["sdf_blob"], scene["vol_cl"], pts_random, variant=0)["sdf"][:, None]
+        sc = o["scalars"]                            # [alpha_sum.mean(), alpha_sum.sum() / (R S), gradient error, evaluated points]: one tiny kernel inside the call
+        return {"depth": o["depth"][:, None], "color_fine": o["color"], "color_fine_mask": o["color_mask"].view(torch.bool)[:, None], "color_outside": None,
+                "color_outside_mask": None, "color_mlp": None, "color_mlp_mask": None,
+                "variance": _attr_cache(var, "_o2345_var_t", (str(dev),), lambda: torch.tensor(1.0 / inv_s, device=dev)),
                 "cdf_fine": o["cdf"].t(), "depth_variance": o["depth_var"][:, None], "weights_sum": o["weights_sum"][:, None],
-                "weights_max": o["weights_max"][:, None], "alpha_sum": o["alpha_sum"].mean(), "alpha_mean": o["alpha_sum"].sum() / (R * S),
-                "gradients": o["grad"].permute(1, 0, 2), "weights": o["weights"].t(), "gradient_error_fine": ge[0] / (ge[1] + 1e-5),
-                "inside_sphere": pm, "sdf": o["sdf"].t().reshape(-1, 1), "sdf_random": sdf_random, "blended_color_patch": None,
+                "weights_max": o["weights_max"][:, None], "alpha_sum": sc[0], "alpha_mean": sc[1],
+                "gradients": o["grad"].permute(1, 0, 2), "weights": o["weights"].t(), "gradient_error_fine": sc[2],
+                "inside_sphere": o["pm"].t(), "sdf": o["sdf"].t().reshape(-1, 1), "sdf_random": sdf_random, "blended_color_patch": None,
                 "blended_color_patch_mask": None, "weights_sum_fg": o["weights_sum"][:, None]}
 
     @torch.no_grad()
@@ -168,7 +199,9 @@ class SparseNeuSRenderer(nn.Module):
             e = torch.nn.functional.interpolate((1 - occupancy_mask)[None, None].float(), [resolution] * 3, mode="nearest")[0, 0] > 0
             u = torch.where(e.to(u.device), torch.full_like(u, -100.0), u)
         v, t = ops.marching_cubes(u.contiguous(), float(threshold))
+        # the reference returns numpy (vertices float64 in world units, triangles, u): three copies into pinned memory, one synchronisation
+        vh, th, uh = ops.to_host_numpy(v, t, u)
         bmin = torch.as_tensor(bound_min).double().cpu().numpy()
         bmax = torch.as_tensor(bound_max).double().cpu().numpy()
-        verts = v.cpu().numpy() / (resolution - 1.0) * (bmax - bmin)[None, :] + bmin[None, :]
-        return verts, t.cpu().numpy(), u.cpu().numpy()
+        verts = vh / (resolution - 1.0) * (bmax - bmin)[None, :] + bmin[None, :]
+        return verts, th, uh

@@ -13,4 +13,5 @@ def marching_cubes(volume, isovalue):
     u = volume if torch.is_tensor(volume) else torch.from_numpy(np.ascontiguousarray(volume, dtype=np.float32))
     u = u.to("cuda", torch.float32).contiguous()
     v, t = ops.marching_cubes(u, float(isovalue))
-    return v.cpu().numpy(), t.cpu().numpy()
+    vh, th = ops.to_host_numpy(v, t)
+    return vh, th

@@ -232,7 +232,7 @@ def _maps(cmaps):
 
 
 def color_points(blob, vol_cl, maskvol, cmaps, proj, cam_pos, pts, query_cam=None, normals=None, index=None, n_dev=None,
-                 want_nviews=True, mfma=False):
+                 want_nviews=True, mfma="x3", stats=None):
     RW = _COL[blob.data_ptr()]
     D = vol_cl.shape[0]
     fm, cm = _maps(cmaps)
@@ -266,8 +266,8 @@ def color_from_features(blob, geometry_feat, rgb_feat, ray_diff, mask, x3=True, 
 
 
 def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64, inv_s=None, alpha_inter_ratio=1.0, background=1.0,
-                query_cam=None, want_z=False, t_rand=None):
-    W, RW = _SDF[scene["sdf_blob"].data_ptr()], _COL[scene["color_blob"].data_ptr()]
+                query_cam=None, want_z=False, t_rand=None, sample_dist=None, want_scalars=False, color_stats=None):
+    W, RW = _SDF[scene["sdf_blob"].data_ptr()], _COL[scene["color_x3_blob"].data_ptr()]
     D = scene["vol_cl"].shape[0]
     fm, cm = _maps(scene["cmaps"])
     q = torch.eye(4)
@@ -287,7 +287,13 @@ def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64,
              color_mask=r["color_fine_mask"][:, 0].to(torch.uint8))
     if want_z:
         o["z_vals"] = r["z_vals"].t().contiguous()
+    if want_scalars:
+        o["scalars"] = torch.stack([o["alpha_sum"].mean(), o["alpha_sum"].sum() / (R * S), ge[:, 0].sum() / (ge[:, 1].sum() + 1e-5), pm.sum()]).float()
     return o
+
+
+def camera_terms(intrinsics, w2cs):
+    return torch.matmul(intrinsics, w2cs[:, :3, :]).contiguous().float(), torch.inverse(w2cs)[:, :3, 3].contiguous().float()
 
 
 def marching_cubes(u, iso=0.0, index_dtype=torch.int64):
@@ -309,7 +315,7 @@ def install(monkeypatch):
     costreg = importlib.import_module("one-2-3-45_amd.costreg")
     featurenet = importlib.import_module("one-2-3-45_amd.featurenet")
     for name in ("costvol_index", "costvol_gather", "visible_count_list", "costvol_gather_list", "build_index_grid", "scatter_dense", "sdf_mlp",
-                 "pack_color_maps", "color_points", "color_from_features", "project_features", "render_rays", "marching_cubes", "prune_dilate", "sparse_downsample", "sparse_conv3d", "bn_act_rows", "fpn_level", "pyramid_pack", "conv2d", "conv2d_pack", "conv_x3", "scale_shift_act", "sdf_grid_tables"):
+                 "pack_color_maps", "color_points", "color_from_features", "project_features", "render_rays", "camera_terms", "marching_cubes", "prune_dilate", "sparse_downsample", "sparse_conv3d", "bn_act_rows", "fpn_level", "pyramid_pack", "conv2d", "conv2d_pack", "conv_x3", "scale_shift_act", "sdf_grid_tables"):
         monkeypatch.setattr(ops, name, globals()[name])
     spnn = importlib.import_module("one-2-3-45_amd.shims.torchsparse.nn")
     monkeypatch.setattr(spnn, "_require_device", lambda t: None)
@@ -324,7 +330,8 @@ def install(monkeypatch):
         _SDF[arr.ctypes.data] = {k: _t(v) for k, v in W.items()}
         return arr
     monkeypatch.setattr(weights, "pack_sdf_blob", pack_sdf_reg)
-    for fn in ("pack_color_blob", "pack_color_mfma_blob", "pack_color_x3_blob"):
+    monkeypatch.setattr(weights, "CACHE_ENABLED", False)      # the registry below is keyed by the address of the array a packer returned
+    for fn in ("pack_color_mfma_blob", "pack_color_x3_blob"):
         orig = getattr(weights, fn)
 
         def reg(sd, _orig=orig):

@@ -19,15 +19,52 @@ def test_cabi_exports_every_declared_symbol():
     protos = L.parse_header()
     assert len(protos) >= 30 and "o2345_render_rays" in protos and "o2345_marching_cubes_emit" in protos
     lib = L.lib()                                    # raises if the .so is missing or a declared symbol is not exported
-    assert lib.o2345_version() >= 100
+    assert lib.o2345_version() == L.ABI_VERSION == 200
     assert lib.o2345_sdf_blob_floats() == pkg.weights.SDF_BLOB_FLOATS
-    assert lib.o2345_color_blob_floats() == pkg.weights.COLOR_BLOB_FLOATS
+    assert not hasattr(lib, "o2345_color_points") and "o2345_color_stats_enable" not in protos      # ABI 2.0: VALU colour kernel and library-global counters are gone
     assert lib.o2345_color_mfma_blob_floats() == pkg.weights.CM_BLOB_FLOATS
     assert lib.o2345_color_x3_blob_floats() == pkg.weights.CX_BLOB_FLOATS
     assert lib.o2345_costvol_workspace_bytes(128, 128, 128) > 0
     # error convention: non-zero status + message, no exception from C
     rc = lib.o2345_sdf_mlp(0, None, None, 8, None, None, None, 10, 0, 1.0, None, None, None, None, None)
     assert rc != 0 and b"null pointer" in lib.o2345_last_error()
+
+
+def test_render_io_has_one_declaration_and_the_binding_checks_it(tmp_path):
+    """O2345RenderIO is declared in include/o2345.h only: csrc/ compiles that header (common.h includes it), the ctypes Structure is generated from its
+    text, and the loaded library's own sizeof / offsetof table is compared at load time.  A field added to ONE side only must fail loudly."""
+    import ctypes
+    import re
+    L = importlib.import_module("one-2-3-45_amd._lib")
+    lib = L.lib()
+    fields = L.parse_struct("O2345RenderIO")
+    names = [f for f, _ in fields]
+    assert "sdf_mode" in names and "sdf_bf16" not in names and "color_blob" not in names and names[0] == "sdf_blob" and names[-1] == "color_stats"
+    assert lib.o2345_render_io_layout(None, 0) == len(fields) and lib.o2345_render_io_size() == ctypes.sizeof(L.RenderIO)
+    # no private copy of the struct anywhere in the library sources
+    import glob
+    import os
+    for f in glob.glob(os.path.join(L.HERE, "csrc", "*")):
+        assert not re.search(r"struct\s+O2345RenderIO\s*\{", open(f).read()), f
+    # a header that gained a field the library was not compiled with (or lost one, or reordered two): the load-time check raises
+    src = open(L.HEADER).read()
+    for mutate in (lambda t: t.replace("int R, n_samples, n_importance;", "int R, n_samples, n_importance; int new_field;"),
+                   lambda t: t.replace("    const float* t_rand;", "    /* removed */", 1),
+                   lambda t: t.replace("float near, far;", "float far, near; float extra;")):
+        hp = tmp_path / "o2345_mut.h"
+        hp.write_text(mutate(src))
+        assert hp.read_text() != src
+
+        class Mut(ctypes.Structure):
+            _fields_ = L.parse_struct("O2345RenderIO", str(hp))
+        orig = L.RenderIO
+        L.RenderIO = Mut
+        try:
+            with pytest.raises(RuntimeError, match="layout mismatch"):
+                L.check_render_io_layout(lib)
+        finally:
+            L.RenderIO = orig
+    L.check_render_io_layout(lib)
 
 
 def test_import_hook_and_shims():

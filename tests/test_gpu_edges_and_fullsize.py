@@ -58,7 +58,7 @@ def _tiny_scene(s):
     t = lambda a: torch.as_tensor(np.asarray(a)).to(dev)
     sc = s["sc"]
     proj, cam_pos = pipeline.camera_terms(t(sc["intrinsics"]), t(sc["w2cs"]))
-    return dict(sdf_blob=t(pkg.weights.pack_sdf_blob(s["sdfW"])), color_blob=t(pkg.weights.pack_color_blob(s["color_sd"])),
+    return dict(sdf_blob=t(pkg.weights.pack_sdf_blob(s["sdfW"])),
                 color_mfma_blob=t(pkg.weights.pack_color_mfma_blob(s["color_sd"])), vol_cl=s["dense"][0].permute(1, 2, 3, 0).contiguous().to(dev),
                 maskvol=s["mask"][0, 0].reshape(-1).contiguous().to(dev), cmaps=ops.pack_color_maps(t(s["fmaps"]), t(sc["images"])), proj=proj,
                 cam_pos=cam_pos)
@@ -104,11 +104,12 @@ def test_zero_points_and_tiny_grids():
 
 @pytest.mark.parametrize("kernel", ["pts", "tiles"])
 @pytest.mark.parametrize("V", [1, 2, 3, 7])
-def test_colour_kernels_odd_view_counts_and_degenerate_points(V, kernel, monkeypatch):
+def test_colour_kernels_odd_view_counts_and_degenerate_points(V, kernel, lib_instance):
     """View counts that are not a power of two (V = 1: mean = the view, variance 0), a single point, a device-side count of zero, points outside
     the volume / seen by no view (all pooling weights 0 -> uniform softmax over zero colours), in both matrix-core kernels, vs the oracle."""
     from scene_util import color_t
-    monkeypatch.setenv("O2345_COLOR_KERNEL", kernel)
+    if kernel == "tiles":                                       # test-only build variant (libo2345_hip_tiles.so) since round 4
+        lib_instance({"O2345_COLOR_KERNEL": "tiles"}, variant="tiles")
     s = small_scene(V=8, HW=40, D=16)
     sc = s["sc"]
     t = lambda a: torch.as_tensor(np.asarray(a)).to(dev)
@@ -345,7 +346,7 @@ def _oracle_args_from(ov_dense, ov_mask, fmaps, wt, sc):
 
 
 def _scene_from(wt, vol_cl, maskvol, cmaps, proj, cam_pos):
-    return dict(sdf_blob=wt.sdf_blob, color_blob=wt.color_blob, color_mfma_blob=wt.color_mblob, color_x3_blob=wt.color_xblob, vol_cl=vol_cl,
+    return dict(sdf_blob=wt.sdf_blob, color_mfma_blob=wt.color_mblob, color_x3_blob=wt.color_xblob, vol_cl=vol_cl,
                 maskvol=maskvol, cmaps=cmaps, proj=proj, cam_pos=cam_pos)
 
 

@@ -92,11 +92,25 @@ def test_render_and_mesh(S):
     for k in ("color_fine", "depth", "weights_sum", "depth_variance"):
         assert rel(outp[k], gp["ren_" + k]) < 1e-3, "perturbed " + k
     assert rel(outp["color_fine"], g["ren_color_fine"]) > 1e-3
-    with pytest.raises(NotImplementedError):       # per-ray near / far are refused loudly, never reduced to element 0
-        S["ren"].render(T(G["ro"]), T(G["rd"]), torch.linspace(0.1, 0.2, len(G["ro"])).to(S["dev"]), 1.0, S["sdf"], S["rnet"], lod=0,
-                        perturb_overwrite=0, conditional_volume=dense, conditional_valid_mask_volume=mask, feature_maps=T(G["fmaps"]),
-                        color_maps=T(sc["images"]), w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW],
-                        query_c2w=T(sc["query_c2w"])[None])
+    # per-ray near / far (the reference's [N_rays, 1] form, sparse_neus_renderer.py:484-490): rays with two different (near, far) pairs of equal
+    # length in ONE call == the two scalar calls on the corresponding rays (ABI 2.0; ABI 1.x refused this form)
+    kw = dict(perturb_overwrite=0, background_rgb=1.0, alpha_inter_ratio=1.0, lod=0, conditional_volume=dense, conditional_valid_mask_volume=mask,
+              feature_maps=T(G["fmaps"]), color_maps=T(sc["images"]), w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW],
+              query_c2w=T(sc["query_c2w"])[None], if_render_with_grad=False)
+    ro, rd = T(G["ro"]), T(G["rd"])
+    n = ro.shape[0]
+    n0, f0 = float(sc["query_near_far"][0]), float(sc["query_near_far"][1])
+    near_r = torch.full((n, 1), n0, device=S["dev"])
+    far_r = torch.full((n, 1), f0, device=S["dev"])
+    near_r[n // 2:] += 0.03125
+    far_r[n // 2:] += 0.03125
+    both = S["ren"].render(ro, rd, near_r, far_r, S["sdf"], S["rnet"], **kw)
+    lo = S["ren"].render(ro[:n // 2], rd[:n // 2], n0, f0, S["sdf"], S["rnet"], **kw)
+    hi = S["ren"].render(ro[n // 2:], rd[n // 2:], n0 + 0.03125, f0 + 0.03125, S["sdf"], S["rnet"], **kw)
+    for k in ("color_fine", "depth", "weights_sum"):
+        assert rel(both[k][:n // 2], lo[k].cpu().numpy()) < 1e-5 and rel(both[k][n // 2:], hi[k].cpu().numpy()) < 1e-5, "per-ray near/far " + k
+    with pytest.raises(ValueError):                 # near / far of a length that is neither 1 nor N_rays
+        S["ren"].render(ro, rd, torch.linspace(0.1, 0.2, n - 1).to(S["dev"]), 1.0, S["sdf"], S["rnet"], **kw)
     R = G["cfg"]["grid_R"]
     v, t, u = S["ren"].extract_geometry(S["sdf"], torch.tensor([-1.0] * 3), torch.tensor([1.0] * 3), resolution=R, threshold=0, device=S["dev"],
                                         conditional_volume=dense, lod=0)

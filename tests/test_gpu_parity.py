@@ -48,7 +48,7 @@ def dev_scene(s, dev, ops):
     cam_pos = torch.inverse(w2c)[:, :3, 3].contiguous().to(dev)
     cmaps = ops.pack_color_maps(t(s["fmaps"]).contiguous(), t(sc["images"]).contiguous())
     return dict(feats=feats, vol_cl=vol_cl, maskvol=maskvol, proj=proj, cam_pos=cam_pos, cmaps=cmaps,
-                sdf_blob=t(pkg.weights.pack_sdf_blob(s["sdfW"])), color_blob=t(pkg.weights.pack_color_blob(s["color_sd"])),
+                sdf_blob=t(pkg.weights.pack_sdf_blob(s["sdfW"])),
                 color_mfma_blob=t(pkg.weights.pack_color_mfma_blob(s["color_sd"])),
                 color_x3_blob=t(pkg.weights.pack_color_x3_blob(s["color_sd"])),
                 aff=t(sc["affine_mats"]).contiguous())
@@ -119,8 +119,15 @@ def test_sparse_conv_x3_single_layer(dev, ops, cin, cout, mode):
         x = torch.from_numpy(rng.normal(0, 1, (n1, cin)).astype(np.float32)).to(dev)
         args = (x, g1, cells1, coords, 1)
     ref = ops.sparse_conv3d(mode, *args, K)
-    got = ops.sparse_conv3d_x3(mode, *args, blob, cout)
+    got = ops.sparse_conv3d_x3(mode, *args, blob, cout, identity_rows=(mode == 0))       # mode 0: the level's own list -> the brick kernel for 32 -> 16
     close(got, ref, rel=2e-5, what=f"sparse conv x3 {cin}->{cout} mode {mode}")
+    if mode == 0:
+        # without the caller's identity-row guarantee the gather form runs and honours ANY out_coords: a reversed subset of the sites
+        sub = torch.arange(len(xyz) - 1, -1, -3, device=dev)
+        got_sub = ops.sparse_conv3d_x3(0, x, grid0, (D, D, D), coords[sub].contiguous(), 1, blob, cout)
+        close(got_sub, ref[sub], rel=2e-5, what=f"sparse conv x3 {cin}->{cout} on a reordered subset of the output sites")
+        with pytest.raises(ValueError):
+            ops.sparse_conv3d_x3(0, x, grid0, (D, D, D), coords[sub].contiguous(), 1, blob, cout, identity_rows=True)
     # the oracle: level objects + kernel maps of oracle/recon.py (down: outputs on the coarse level; up: the down map with roles swapped)
     L0 = O.SparseLevel(torch.from_numpy(xyz).long(), 1)
     L1 = O.downsample_coords(L0)
@@ -427,22 +434,19 @@ def test_marching_cubes(dev, ops):
     assert v.shape[0] == 0 and t.shape[0] == 0
 
 
-@pytest.mark.parametrize("mfma,V,kernel", [(False, 4, None), (True, 4, "tiles"), (True, 8, "tiles"), (False, 8, None), (True, 12, "tiles"), (True, 32, "tiles"),
+@pytest.mark.parametrize("mfma,V,kernel", [(True, 4, "tiles"), (True, 8, "tiles"), (True, 12, "tiles"), (True, 32, "tiles"),
                                            ("x3", 4, "tiles"), ("x3", 8, "tiles"), ("x3", 12, "tiles"), ("x3", 32, "tiles"),
                                            (True, 4, "pts"), (True, 5, "pts"), (True, 8, "pts"), (True, 32, "pts"),
-                                           ("x3", 4, "pts"), ("x3", 5, "pts"), ("x3", 8, "pts"), ("x3", 12, "pts"), ("x3", 32, "pts"),
-                                           ("x3", 5, None), ("x3", 8, None)])
-def test_color_points(dev, ops, mfma, V, kernel, monkeypatch):
-    """Both matrix-core kernels in both numerical forms (+ the VALU kernel): "tiles" = k_color_mfma (columns = (point, view) pairs; V = 4 / 8 /
-    12 / 32 exercise its G = 4 / 8 / 16 / 32 lane groups incl. padded views for V = 12), "pts" = k_color_pts (columns = points, any V);
-    None = the library's own choice (k_color_pts when the view count is not a power of two)."""
-    if kernel is not None:
-        monkeypatch.setenv("O2345_COLOR_KERNEL", kernel)
-    else:
-        monkeypatch.delenv("O2345_COLOR_KERNEL", raising=False)
+                                           ("x3", 4, "pts"), ("x3", 5, "pts"), ("x3", 8, "pts"), ("x3", 12, "pts"), ("x3", 32, "pts")])
+def test_color_points(dev, ops, mfma, V, kernel, lib_instance):
+    """The colour kernel in both numerical forms: "pts" = k_color_pts (columns = points, any V: the product kernel); "tiles" = k_color_mfma (columns =
+    (point, view) pairs; V = 4 / 8 / 12 / 32 exercise its G = 4 / 8 / 16 / 32 lane groups incl. padded views for V = 12) -- a TEST-ONLY build variant
+    since round 4 (libo2345_hip_tiles.so, -DO2345_TILES_KERNEL, selected by O2345_COLOR_KERNEL=tiles), kept as the independent second implementation."""
+    if kernel == "tiles":
+        assert b"color_tiles=1" in lib_instance({"O2345_COLOR_KERNEL": "tiles"}, variant="tiles").o2345_knobs()
     s = small_scene(V=V, HW=40, D=16) if V != 4 else small_scene()
     d = dev_scene(s, dev, ops)
-    blob = d["color_x3_blob"] if mfma == "x3" else (d["color_mfma_blob"] if mfma else d["color_blob"])
+    blob = d["color_x3_blob"] if mfma == "x3" else d["color_mfma_blob"]
     sc = s["sc"]
     rng = np.random.default_rng(2)
     pts = torch.from_numpy(rng.uniform(-0.9, 0.9, (3000, 3)).astype(np.float32))
@@ -484,7 +488,7 @@ def test_render(dev, ops, nrays, precision):
     variance = torch.tensor(0.2)
     inv_s = float(torch.exp(variance * 10.0).clip(1e-6, 1e6))
     qcam = torch.from_numpy(sc["query_c2w"][:3, 3].copy())
-    scene = {k: d[k] for k in ("sdf_blob", "color_blob", "color_mfma_blob", "color_x3_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos")}
+    scene = {k: d[k] for k in ("sdf_blob", "color_mfma_blob", "color_x3_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos")}
     scene["sdf_precision"] = scene["color_precision"] = precision
     out = ops.render_rays(scene, torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev), near, far, 64, 64, inv_s, 1.0, 1.0,
                           qcam.to(dev), want_z=True)
@@ -553,7 +557,7 @@ def test_render_trained_regime(dev, ops, variance, air, bg, shift, precision):
     a = _oracle_args(s, shift)
     W = {k: np.array(v) for k, v in s["sdfW"].items()}
     W["b2"][0] += shift
-    scene = {k: d[k] for k in ("color_blob", "color_mfma_blob", "color_x3_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos")}
+    scene = {k: d[k] for k in ("color_mfma_blob", "color_x3_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos")}
     scene["sdf_blob"] = torch.from_numpy(pkg.weights.pack_sdf_blob(W)).to(dev)
     ro, rd = rays_for(s, 96, seed=5)
     res = RC.three_clause(ops, dev, scene, a, torch.from_numpy(ro), torch.from_numpy(rd), float(sc["query_near_far"][0]),
@@ -614,7 +618,7 @@ def test_convolution_precision_is_per_object(dev, ops, monkeypatch):
 
 
 @pytest.mark.parametrize("V", [5, 8, 32])
-def test_view_skipping_is_bit_identical(dev, ops, V, monkeypatch):
+def test_view_skipping_is_bit_identical(dev, ops, V, lib_instance):
     """k_color_pts skips the views that see none of a tile's 32 points (wave-uniform).  The claim is BIT-identity with the kernel that evaluates every
     view (O2345_COLOR_SCHED bit 2), for colours and valid-view counts, on a point set that contains every case: points seen by many views, by one, by
     none (all-masked tiles blend every view uniformly), points outside the volume, tiles whose points disagree about a view, a ragged last tile."""
@@ -631,14 +635,12 @@ def test_view_skipping_is_bit_identical(dev, ops, V, monkeypatch):
     pts = np.concatenate([pts, rng.uniform(-0.5, 0.5, (3, 3)).astype(np.float32)])                                               # ragged last tile
     p = torch.from_numpy(pts).to(dev)
     qcam = torch.from_numpy(sc["query_c2w"][:3, 3].copy()).to(dev)
-    monkeypatch.delenv("O2345_COLOR_KERNEL", raising=False)
     outs = {}
     for sched in ("4", "0", "10", "14"):
-        monkeypatch.setenv("O2345_COLOR_SCHED", sched)
-        ops.color_stats(True)
-        outs[sched] = ops.color_points(d["color_x3_blob"], d["vol_cl"], d["maskvol"], d["cmaps"], d["proj"], d["cam_pos"], p, query_cam=qcam, mfma="x3")
-        outs[sched] += (ops.color_stats_read(),)
-        ops.color_stats(False)
+        lib_instance({"O2345_COLOR_SCHED": sched})          # a library instance per knob value: the knobs are read once per instance
+        st = ops.color_stats_buffer(dev)                    # caller-owned work counters (no library state)
+        outs[sched] = ops.color_points(d["color_x3_blob"], d["vol_cl"], d["maskvol"], d["cmaps"], d["proj"], d["cam_pos"], p, query_cam=qcam, mfma="x3", stats=st)
+        outs[sched] += (ops.color_stats_read(st),)
     ref = outs["4"]
     assert ref[2]["pairs_network"] == ref[2]["tiles"] * V                      # bit 2: every (tile, view) pair evaluated
     for k in ("0", "10"):

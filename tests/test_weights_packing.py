@@ -65,16 +65,37 @@ def test_x3_blob_emulation(pkg):
     assert np.all(np.abs(hi.astype(np.float64) + lo - x) <= np.maximum(np.abs(x) * 2.0 ** -20, 6e-8))
 
 
-def test_color_blob_layout(pkg):
-    sd = pkg.weights.init_color_state_dict(0)
-    blob = pkg.weights.pack_color_blob(sd)
-    S = pkg.weights.COLOR_SEGS
-    assert blob.size == pkg.weights.COLOR_BLOB_FLOATS
-    w = sd["base_fc.0.weight"]
-    assert blob[S["base0_w"] + 17 * 64 + 5] == w[5, 17]
-    assert blob[S["rd1_wT"] + 7 * 16 + 3] == sd["ray_dir_fc.2.weight"][7, 3]
-    assert blob[S["vis1_w"] + 4 * 36 + 32] == sd["vis_fc.2.weight"][32, 4]
-    assert blob[S["s"]] == np.float32(0.2)
+def test_cached_pack_is_content_keyed(pkg, tmp_path, monkeypatch):
+    """weights.cached_pack: the same parameters -> the same blob without re-packing (process memo, then the disk cache of a later process); changed
+    parameters -> a different key; a truncated cache file is recomputed, never trusted."""
+    import os
+    W = pkg.weights
+    monkeypatch.setenv("O2345_CACHE_DIR", str(tmp_path))
+    monkeypatch.setattr(W, "_MEM_CACHE", {})
+    sd = W.init_color_state_dict(3)
+    calls = []
+    orig = W.pack_color_x3_blob
+    monkeypatch.setattr(W, "pack_color_x3_blob", lambda s_: calls.append(1) or orig(s_))
+    a = W.packed_color_x3_blob(sd)
+    b = W.packed_color_x3_blob({k: np.array(v) for k, v in sd.items()})          # equal content, different objects
+    assert len(calls) == 1 and a is b and np.array_equal(a, orig(sd))
+    files = [f for f in os.listdir(tmp_path) if f.startswith("color_x3_")]
+    assert len(files) == 1
+    W._MEM_CACHE.clear()                                                         # "a later process": served from disk
+    c = W.packed_color_x3_blob(sd)
+    assert len(calls) == 1 and np.array_equal(c, a)
+    sd2 = dict(sd)
+    sd2["s"] = np.float32(0.25)
+    d = W.packed_color_x3_blob(sd2)
+    assert len(calls) == 2 and not np.array_equal(d, a)
+    W._MEM_CACHE.clear()
+    with open(os.path.join(tmp_path, files[0]), "r+b") as f:
+        f.truncate(100)
+    e = W.packed_color_x3_blob(sd)
+    assert len(calls) == 3 and np.array_equal(e, a)
+    monkeypatch.setenv("O2345_CACHE_DIR", "off")
+    W._MEM_CACHE.clear()
+    assert W.cache_dir() is None and np.array_equal(W.packed_sdf_blob(W.init_sdf_weights(1)), W.pack_sdf_blob(W.init_sdf_weights(1)))
 
 
 def test_color_mfma_blob_emulation_matches_oracle(pkg):
