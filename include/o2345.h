@@ -190,10 +190,10 @@ int o2345_ray_coarse_jitter(const float* rays_o, const float* rays_d, int R, flo
 int o2345_ray_coarse_per_ray(const float* rays_o, const float* rays_d, int R, const float* near_ray, const float* far_ray, int S,
                              const float* t_rand, float* z, float* pts, void* stream);
 /* up_sample + sample_pdf of one round (:73-115, render_utils.py:8-51): z / sdf [S][R] sorted per ray -> new_z [n_imp][R], their points, new_sdf = 100
- * (the cat_z_vals default), and the list of new points inside the mask (slots t * R + r) with its device-side count.  (ABI 1.x took a scratch
- * array `wbuf`: the section weights live in LDS now.) */
+ * (the cat_z_vals default), and the list of new points inside the mask (slots t * R + r) with its device-side count.  wbuf: scratch [S][R] floats for
+ * the streaming kernel, or NULL: the LDS-staged kernel then runs whatever R is (the two give bit-identical results; csrc/render.hip). */
 int o2345_ray_upsample(const float* rays_o, const float* rays_d, int R, const float* z, const float* sdf, int S,
-                       float inv_s, const float* maskvol, int D, int n_imp, float* new_z, float* new_pts,
+                       float inv_s, const float* maskvol, int D, float* wbuf, int n_imp, float* new_z, float* new_pts,
                        float* new_sdf, int32_t* list, int32_t* count_dev, void* stream);
 int o2345_ray_merge(int R, float* z, float* sdf, int S, float* new_z, float* new_sdf, int n_new, void* stream);
 /* finalize: mid points, section lengths, occupancy of the mid points and the list of occupied slots; every slot of sdf / grad / rgb receives the

@@ -21,7 +21,8 @@ int o2345_version(void) { return 200; }     // 2.0: see include/o2345.h (1.5: o2
 
 const char* o2345_knobs(void) {
     static const struct Text { char s[160]; Text() { const o2345::Knobs& k = o2345::knobs();
-        snprintf(s, sizeof s, "list_sort=%d sparse_brick=%d flat_sched=%d color_tiles=%d color_sched=%d", k.list_sort, k.sparse_brick, k.flat_sched, k.color_tiles, k.color_sched); } } t;
+        snprintf(s, sizeof s, "list_sort=%d sparse_brick=%d flat_sched=%d color_tiles=%d color_sched=%d ray_stream_min=%lld", k.list_sort, k.sparse_brick, k.flat_sched,
+                 k.color_tiles, k.color_sched, k.ray_stream_min); } } t;
     return t.s;
 }
 

@@ -94,15 +94,20 @@ __device__ __forceinline__ int block_prefix(bool pred, int* lds_wave_tot /*[NWAV
 //   O2345_SPARSE_BRICK=0  finest sparse convolution in the gather form instead of the LDS-tiled brick form
 //   O2345_FLAT_SCHED=1    persistent network kernels: flat block-interleaved tile schedule (odd grid) instead of one eighth of the list per XCD
 //   O2345_COLOR_KERNEL=tiles  (only in a -DO2345_TILES_KERNEL test build) the (point, view)-column colour kernel instead of k_color_pts
+//   O2345_RAY_STREAM_MIN=n  render call: ray batches of at least n rays run the streaming sampler kernels (one lane per ray, lists read from global
+//                         memory at full occupancy), smaller ones the sixteen-lanes-per-ray kernels (default 4096; 0 = always streaming, a huge value = never)
 struct Knobs {
     bool list_sort, sparse_brick, flat_sched, color_tiles;
     int color_sched;
+    long long ray_stream_min;
 };
 inline const Knobs& knobs() {
     static const Knobs k = [] {
         auto is = [](const char* name, char c) { const char* e = getenv(name); return e && e[0] == c; };
         const char* cs = getenv("O2345_COLOR_SCHED");
-        return Knobs{!is("O2345_LIST_SORT", '0'), !is("O2345_SPARSE_BRICK", '0'), is("O2345_FLAT_SCHED", '1'), is("O2345_COLOR_KERNEL", 't'), cs ? atoi(cs) : 10};
+        const char* rs = getenv("O2345_RAY_STREAM_MIN");
+        return Knobs{!is("O2345_LIST_SORT", '0'), !is("O2345_SPARSE_BRICK", '0'), is("O2345_FLAT_SCHED", '1'), is("O2345_COLOR_KERNEL", 't'), cs ? atoi(cs) : 10,
+                     rs ? atoll(rs) : 4096};
     }();
     return k;
 }

@@ -73,20 +73,19 @@ __global__ void k_quirk_first100(int* count, int* list, int R, int S) {
     if (t == 0) *count = (100 < S ? 100 : S);
 }
 
-// ---- one round of the hierarchical sampler, 64 rays per wave, the rays' lists staged in LDS -------------------------------------------------------
-// Round-3 kernels walked a ray's samples straight from the sample-major global lists: every step of the serial chains (transmittance, CDF walk,
-// back-to-front merge) was a DEPENDENT trip to L2 / HBM, 60 - 110 of them per ray and launch -- 81 / 40 / 95 us per launch for one 512-ray chunk
-// of the reference's val loop and 2.9 ms per 262,144 rays with one lane per ray.  Here a wave first copies the lists of its 64 rays into LDS with
-// every load in flight (rows of 256 bytes, lane = ray: a[row * 64 + lane]; a lane only ever touches its own column, so there are no bank conflicts
-// and no barriers), runs the chains out of LDS, and writes results back as whole rows.  Three things are fused on top of that:
-//   * cat_z_vals of the PREVIOUS round (merge of its 16 new samples, now with their SDF values) happens in LDS at the start of the next kernel:
-//     the merged list is written back once, and the separate merge launch with its two passes over the lists is gone;
-//   * the occupancy flag of every sample point travels with the list (one byte per sample, produced where the point is produced) instead of
-//     being gathered from the mask volume again in every round;
-//   * the last merge is fused with render_core's head (mid points, section lengths, occupancy, defaults, occupied-point list).
-// The arithmetic of every chain is that of render_math.h (shared with the host-check build), in the same order.
-constexpr int RT = 64;                              // rays per wave / tile
-constexpr int RAY_LDS_ROW_BYTES = RT * (4 + 4 + 1);  // z | sdf (later: section weight) | occupancy flag
+// ---- one round of the hierarchical sampler (up_sample + sample_pdf, preceded by the cat_z_vals of the previous round; or that merge + render_core's head)
+// Round 3 ran three kernels per round (up-sample, merge, and the SDF network between them) that walked a ray's samples straight from the sample-major
+// global lists, one lane per ray: every step of the serial chains (transmittance, CDF walk, back-to-front merge) was a DEPENDENT trip to L2 / HBM, 60 - 110
+// of them per ray and launch -- 2.9 ms per 262,144 rays, and 81 / 40 / 95 us per launch for one 512-ray chunk of the reference's val loop.  Round 4:
+//   * cat_z_vals of the PREVIOUS round (its 16 new samples, now with their SDF values) is fused into the next kernel as a rank merge, and the last
+//     merge into render_core's head (mid points, section lengths, occupancy, defaults, occupied-point list): four launches and two passes over the lists less;
+//   * the occupancy flag of every sample point travels with the list (one byte per sample, written where the point is produced) instead of being
+//     gathered from the mask volume again in every round;
+//   * two forms of the same round, selected by the batch size (knobs().ray_stream_min), sharing render_math.h and bit-identical to each other:
+//     k_ray_stream (large batches: one lane per ray, static access pattern, blocks of 8 rows in flight, full occupancy -> HBM-bound) and
+//     k_ray_group (small batches: sixteen lanes per ray, only the two scans serial).
+constexpr int NFIX = 16;                             // new samples per round held in registers (n_importance / 4 of the released configuration)
+constexpr int RM_UPSAMPLE = 0, RM_FINALIZE = 1, RM_MERGE_ONLY = 2;
 
 struct RoundArgs {
     RayGeom g;
@@ -100,71 +99,65 @@ struct RoundArgs {
     // finalize
     float sample_dist;
     float* mid_z; float* dists; float* pts; float* pm; float* o_sdf; float* grad; float* rgb; int defaults_everywhere;
+    int merge_all_lists;                             // finalize + merge: also write the merged sdf / occupancy lists back (nobody reads them after the last round)
 };
 
-struct LdsRay {                                      // accessor of upsample_core (render_math.h) on the staged tile
-    float* zL; float* sL; const uint8_t* mL; int lane; int tmp_row;
-    __device__ __forceinline__ float z(int s) const { return zL[s * RT + lane]; }
-    __device__ __forceinline__ float sdf(int s) const { return sL[s * RT + lane]; }
-    __device__ __forceinline__ float msk(int s, float) const { return (float)mL[s * RT + lane]; }
-    __device__ __forceinline__ void set_w(int s, float v) { sL[s * RT + lane] = v; }      // sdf[s] has been consumed when section s is done
-    __device__ __forceinline__ float w(int s) const { return sL[s * RT + lane]; }
-    __device__ __forceinline__ void out(int t, float v) { zL[(tmp_row + t) * RT + lane] = v; }   // new depths: parked in the free rows behind the list
+// ---- the same round as a STREAMING kernel: one lane per ray, the lists read from global memory ------------------------------------------------
+// Nothing is staged (an LDS-staged form -- 64 rays x 128 rows x 9 bytes per wave -- was measured this round: two waves per CU, 0.82 ms per round at
+// 262,144 rays against 0.36 here): render_math.h's passes touch the lists at static, ascending rows in blocks of 8, so every block is one trip with 24
+// loads in flight, eight waves per SIMD hide those trips, and a round is bound by its HBM traffic.  The section weights go through a global scratch
+// row set (wbuf); in-place rank merge on the global lists (writes of a block of rows never reach a row not yet read).
+struct StreamRay {                                   // accessor of upsample_core on the global lists
+    const float* z_; const float* sdf_; const uint8_t* m_; float* w_; float* out_;
+    size_t R; int r; RayGeom g; const float* maskvol; int D;
+    __device__ __forceinline__ float z(int s) const { return z_[(size_t)s * R + r]; }
+    __device__ __forceinline__ float sdf(int s) const { return sdf_[(size_t)s * R + r]; }
+    __device__ __forceinline__ float msk(int s, float zs) const {
+        if (m_) return (float)m_[(size_t)s * R + r];
+        float x, y, w;
+        ray_point(g, r, zs, x, y, w);
+        return mask_at(maskvol, D, x, y, w) > 0.f ? 1.f : 0.f;
+    }
+    __device__ __forceinline__ void set_w(int s, float v) { w_[(size_t)s * R + r] = v; }
+    __device__ __forceinline__ float w(int s) const { return w_[(size_t)s * R + r]; }
+    __device__ __forceinline__ void out(int t, float v) { out_[(size_t)t * R + r] = v; }
 };
-struct LdsMerge {                                    // accessor of merge_core_fixed
-    float* zL; float* sL; uint8_t* mL; int lane;
-    __device__ __forceinline__ float z(int i) const { return zL[i * RT + lane]; }
-    __device__ __forceinline__ float sdf(int i) const { return sL[i * RT + lane]; }
-    __device__ __forceinline__ unsigned tag(int i) const { return mL[i * RT + lane]; }
-    __device__ __forceinline__ void put(int i, float zv, float sv, unsigned t) { zL[i * RT + lane] = zv; sL[i * RT + lane] = sv; mL[i * RT + lane] = (uint8_t)t; }
+struct GlobalMergeTag {
+    float* z_; float* sdf_; uint8_t* m_; size_t R; int r;
+    __device__ __forceinline__ float z(int i) const { return z_[(size_t)i * R + r]; }
+    __device__ __forceinline__ float sdf(int i) const { return sdf_[(size_t)i * R + r]; }
+    __device__ __forceinline__ unsigned tag(int i) const { return m_ ? m_[(size_t)i * R + r] : 0u; }
+    __device__ __forceinline__ void put(int i, float zv, float sv, unsigned t) {
+        z_[(size_t)i * R + r] = zv; sdf_[(size_t)i * R + r] = sv;
+        if (m_) m_[(size_t)i * R + r] = (uint8_t)t;
+    }
 };
-
-constexpr int RM_UPSAMPLE = 0, RM_FINALIZE = 1, RM_MERGE_ONLY = 2;
-constexpr int NFIX = 16;                             // new samples per round held in registers (n_importance / 4 of the released configuration)
+struct GlobalMergeZ {                               // the LAST cat_z_vals of a render call: only the depths are read again (render_core re-evaluates the SDF at the mid points)
+    float* z_; size_t R; int r;
+    __device__ __forceinline__ float z(int i) const { return z_[(size_t)i * R + r]; }
+    __device__ __forceinline__ float sdf(int) const { return 0.f; }
+    __device__ __forceinline__ unsigned tag(int) const { return 0u; }
+    __device__ __forceinline__ void put(int i, float zv, float, unsigned) { z_[(size_t)i * R + r] = zv; }
+};
 
 template <int MODE, bool MERGE>
-__global__ __launch_bounds__(RT) void k_ray_round(RoundArgs a) {
-    extern __shared__ float lds[];
-    const int R = a.g.R, lane = threadIdx.x;
-    const int r = blockIdx.x * RT + lane;
+__global__ __launch_bounds__(256) void k_ray_stream(RoundArgs a, float* __restrict__ wbuf) {
+    const int R = a.g.R;
+    const int r = blockIdx.x * 256 + threadIdx.x;
     const bool live = r < R;
-    const int rr = live ? r : R - 1;                 // lanes past the last ray shadow it (reads only)
-    const int rows = a.S + (MERGE ? NFIX : 0) + (MODE == RM_UPSAMPLE ? a.n_imp : 0);
-    float* zL = lds;
-    float* sL = zL + rows * RT;
-    uint8_t* mL = reinterpret_cast<uint8_t*>(sL + rows * RT);
+    const int rr = live ? r : R - 1;
     int S = a.S;
-    // ---- stage the lists: independent loads, 8 rows in flight per array
-#pragma unroll 8
-    for (int s = 0; s < S; ++s) {
-        zL[s * RT + lane] = a.z[(size_t)s * R + rr];
-        sL[s * RT + lane] = a.sdf[(size_t)s * R + rr];
-    }
-    const bool need_mask = MODE == RM_UPSAMPLE;
-    if (need_mask || (MERGE && a.msk)) {
-        if (a.msk) {
-#pragma unroll 8
-            for (int s = 0; s < S; ++s) mL[s * RT + lane] = a.msk[(size_t)s * R + rr];
-        } else {
-#pragma unroll 8
-            for (int s = 0; s < S; ++s) {
-                float x, y, w;
-                ray_point(a.g, rr, zL[s * RT + lane], x, y, w);
-                mL[s * RT + lane] = mask_at(a.maskvol, a.D, x, y, w) > 0.f ? 1 : 0;
-            }
-        }
-    }
-    // ---- cat_z_vals of the previous round's samples, in LDS
     if (MERGE) {
         float nz[NFIX], ns[NFIX];
         unsigned nt[NFIX];
 #pragma unroll
         for (int j = 0; j < NFIX; ++j) {
             nz[j] = a.new_z[(size_t)j * R + rr];
-            ns[j] = a.new_sdf[(size_t)j * R + rr];
-            nt[j] = a.new_msk ? a.new_msk[(size_t)j * R + rr] : 0u;
+            const bool z_only = MODE == RM_FINALIZE && !a.merge_all_lists;
+            ns[j] = z_only ? 0.f : a.new_sdf[(size_t)j * R + rr];
+            nt[j] = (a.new_msk && !z_only) ? a.new_msk[(size_t)j * R + rr] : 0u;
         }
-        if (need_mask && !a.new_msk) {
+        if (MODE == RM_UPSAMPLE && a.msk && !a.new_msk) {
 #pragma unroll
             for (int j = 0; j < NFIX; ++j) {
                 float x, y, w;
@@ -175,66 +168,62 @@ __global__ __launch_bounds__(RT) void k_ray_round(RoundArgs a) {
         bool sorted = true;
 #pragma unroll
         for (int j = 0; j + 1 < NFIX; ++j) sorted = sorted && !(nz[j] > nz[j + 1]);
-        LdsMerge m{zL, sL, mL, lane};
-        merge_core_fixed<LdsMerge, NFIX>(m, S, nz, ns, nt, !__any(!sorted));
-        S += NFIX;
-        if (live) {
-#pragma unroll 8
-            for (int s = 0; s < S; ++s) {
-                a.z[(size_t)s * R + r] = zL[s * RT + lane];
-                a.sdf[(size_t)s * R + r] = sL[s * RT + lane];
-            }
-            if (a.msk) {
-#pragma unroll 8
-                for (int s = 0; s < S; ++s) a.msk[(size_t)s * R + r] = mL[s * RT + lane];
+        if (live) {                                 // in-place on the global lists: lanes past the last ray must not write
+            if (MODE == RM_FINALIZE && !a.merge_all_lists) {
+                GlobalMergeZ m{a.z, (size_t)R, r};
+                merge_core_fixed<GlobalMergeZ, NFIX>(m, S, nz, ns, nt, sorted);
+            } else {
+                GlobalMergeTag m{a.z, a.sdf, a.msk, (size_t)R, r};
+                merge_core_fixed<GlobalMergeTag, NFIX>(m, S, nz, ns, nt, sorted);
             }
         }
+        S += NFIX;
     }
     if (MODE == RM_UPSAMPLE) {
-        // ---- up_sample + sample_pdf (render_math.h upsample_core) out of LDS; the new depths are parked in rows S .. S + n_imp - 1 of zL
-        LdsRay acc{zL, sL, mL, lane, S};
-        upsample_core(acc, S, a.inv_s, a.n_imp);
+        if (live) {
+            StreamRay acc{a.z, a.sdf, a.msk, wbuf, a.out_z, (size_t)R, r, a.g, a.maskvol, a.D};
+            upsample_core(acc, S, a.inv_s, a.n_imp);
+        }
         ValidBits bits{};
         int cnt = 0;
-        for (int t0 = 0; t0 < a.n_imp; t0 += 8) {                       // points, defaults and occupancy of the new samples: 8 gathers in flight
-            float m8[8];
+        for (int t0 = 0; t0 < a.n_imp; t0 += 8) {
+            float m8[8], z8[8], p8[8][3];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) z8[k] = a.out_z[(size_t)(t0 + k < a.n_imp ? t0 + k : a.n_imp - 1) * R + rr];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int t = t0 + k < a.n_imp ? t0 + k : a.n_imp - 1;
-                const float zn = zL[(S + t) * RT + lane];
-                float x, y, w;
-                ray_point(a.g, rr, zn, x, y, w);
-                m8[k] = mask_at(a.maskvol, a.D, x, y, w);
-                if (live && t0 + k < a.n_imp) {
-                    const size_t slot = (size_t)t * R + r;
-                    a.out_z[slot] = zn;
-                    a.out_pts[3 * slot] = x; a.out_pts[3 * slot + 1] = y; a.out_pts[3 * slot + 2] = w;
-                    a.out_sdf[slot] = 100.f;                             // cat_z_vals default outside the mask (:135)
-                }
+                ray_point(a.g, rr, z8[k], p8[k][0], p8[k][1], p8[k][2]);
+                m8[k] = mask_at(a.maskvol, a.D, p8[k][0], p8[k][1], p8[k][2]);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int t = t0 + k;
                 if (live && t < a.n_imp) {
+                    const size_t slot = (size_t)t * R + r;
+                    a.out_pts[3 * slot] = p8[k][0]; a.out_pts[3 * slot + 1] = p8[k][1]; a.out_pts[3 * slot + 2] = p8[k][2];
+                    a.out_sdf[slot] = 100.f;                             // cat_z_vals default outside the mask (:135)
                     const bool in = m8[k] > 0.f;
-                    if (a.out_msk) a.out_msk[(size_t)t * R + r] = in ? 1 : 0;
+                    if (a.out_msk) a.out_msk[slot] = in ? 1 : 0;
                     if (in) { bits.w[t >> 5] |= 1u << (t & 31); ++cnt; }
                 }
             }
         }
         append_wave(bits, a.n_imp, cnt, R, r, a.list, a.count);
     } else if (MODE == RM_FINALIZE) {
-        // ---- render_core head (:204-231): section lengths, mid points, occupancy of the MID points, defaults, occupied-point list
         ValidBits bits{};
         int cnt = 0;
+        float znext = a.z[rr];
         for (int s0 = 0; s0 < S; s0 += 8) {
-            float m8[8], d8[8], z8[8], p8[8][3];
+            float zc8[9], m8[8], d8[8], z8[8], p8[8][3];
+            zc8[0] = znext;
+#pragma unroll
+            for (int k = 1; k <= 8; ++k) zc8[k] = a.z[(size_t)(s0 + k < S ? s0 + k : S - 1) * R + rr];
+            znext = zc8[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int s = s0 + k < S ? s0 + k : S - 1;
-                const float zc = zL[s * RT + lane];
-                const float d = (s + 1 < S) ? zL[(s + 1) * RT + lane] - zc : a.sample_dist;
-                const float mz = zc + d * 0.5f;
+                const int s = s0 + k;
+                const float d = (s + 1 < S) ? zc8[k + 1] - zc8[k] : a.sample_dist;
+                const float mz = zc8[k] + d * 0.5f;
                 ray_point(a.g, rr, mz, p8[k][0], p8[k][1], p8[k][2]);
                 m8[k] = mask_at(a.maskvol, a.D, p8[k][0], p8[k][1], p8[k][2]);
                 d8[k] = d; z8[k] = mz;
@@ -263,17 +252,263 @@ __global__ __launch_bounds__(RT) void k_ray_round(RoundArgs a) {
     }
 }
 
-// cat_z_vals for a block size other than NFIX: the plain per-ray merge on the global lists (render_math.h merge_ray), occupancy bytes along
-struct GlobalMergeTag {
-    float* z_; float* sdf_; uint8_t* m_; size_t R; int r;
-    __device__ __forceinline__ float z(int i) const { return z_[(size_t)i * R + r]; }
-    __device__ __forceinline__ float sdf(int i) const { return sdf_[(size_t)i * R + r]; }
-    __device__ __forceinline__ unsigned tag(int i) const { return m_ ? m_[(size_t)i * R + r] : 0u; }
-    __device__ __forceinline__ void put(int i, float zv, float sv, unsigned t) {
-        z_[(size_t)i * R + r] = zv; sdf_[(size_t)i * R + r] = sv;
-        if (m_) m_[(size_t)i * R + r] = (uint8_t)t;
+// ---- the same round for SMALL batches: sixteen lanes per ray ---------------------------------------------------------------------------------------
+// A 512-ray chunk of the reference's val loop (trainer_generic.py:415-416) is 8 waves with one lane per ray: every kernel of the round is one wave's
+// ~20 k dependent instructions long whatever the GPU could do in parallel (50 - 130 us per launch with either form above, x 6 launches x 128 chunks per
+// image).  Only TWO things in a round are inherently serial per ray: the running transmittance / weight sum (pass 1) and the running CDF (pass 2) --
+// two scans of ~110 two-operation steps whose order is the reference's order and is kept.  Everything else is element-wise per section / per sample and
+// is spread over the 16 lanes of the ray's group (4 rays per wave, the lists of the 4 rays in LDS, ray-contiguous so that lane l reads row l + 16 i):
+//   merge   rank merge: each existing sample finds #new < it (16 compares against the new block), each new sample its rank in the block and #old <= it
+//           (binary search); out of place, in LDS;
+//   pass 1  alpha_s of every section in parallel (upsample_section_alpha; a section recomputes its predecessor's slope) -> lane 0 runs the T / w / sum scan;
+//   pass 2  pdf = w / sum in parallel -> lane 0 accumulates the CDF in order -> every new sample t does its own searchsorted (binary search) and
+//           interpolation: identical to the forward walk, which stops at the first k with cdf_k > u_t as well;
+//   points, occupancy and the list of the new samples in parallel (one ballot per wave).
+// Same arithmetic per element, same order in the two scans => bit-identical to the other two forms (tests/test_gpu_parity.py).
+constexpr int GL = 16, GR = 4;                       // lanes per ray, rays per wave
+constexpr int GROUP_ARRAYS = 5;
+__host__ __device__ constexpr size_t group_lds_bytes(int rows) { return (size_t)GROUP_ARRAYS * GR * (rows + 1) * sizeof(float); }
+
+template <int MODE, bool MERGE>
+__global__ __launch_bounds__(64) void k_ray_group(RoundArgs a) {
+    extern __shared__ float lds[];
+    const int R = a.g.R, lane = threadIdx.x, sub = lane >> 4, l = lane & 15;
+    const int r = blockIdx.x * GR + sub;
+    const bool live = r < R;
+    const int rr = live ? r : R - 1;
+    int S = a.S;
+    const int cap = S + (MERGE ? NFIX : 0) + 1;
+    float* zM = lds + (size_t)(0 * GR + sub) * cap;   // the (merged) lists of this ray
+    float* sM = lds + (size_t)(1 * GR + sub) * cap;
+    float* mM = lds + (size_t)(2 * GR + sub) * cap;
+    float* xA = lds + (size_t)(3 * GR + sub) * cap;   // new block (merge) -> alpha -> w -> pdf
+    float* cA = lds + (size_t)(4 * GR + sub) * cap;   // old depths (merge) -> cdf
+    const bool need_mask = MODE == RM_UPSAMPLE;
+    auto mask_of = [&](float zs) {
+        float x, y, w;
+        ray_point(a.g, rr, zs, x, y, w);
+        return mask_at(a.maskvol, a.D, x, y, w) > 0.f ? 1.f : 0.f;
+    };
+    if (!MERGE) {
+        for (int i = l; i < S; i += GL) {
+            const float zi = a.z[(size_t)i * R + rr];
+            zM[i] = zi;
+            sM[i] = a.sdf[(size_t)i * R + rr];
+            if (need_mask) mM[i] = a.msk ? (float)a.msk[(size_t)i * R + rr] : mask_of(zi);
+        }
+        __syncthreads();
+    } else {
+        // new block: lane j holds new sample j
+        const float nzj = a.new_z[(size_t)l * R + rr];
+        const float nsj = a.new_sdf[(size_t)l * R + rr];
+        float ntj = 0.f;
+        if (need_mask || a.msk) ntj = a.new_msk ? (float)a.new_msk[(size_t)l * R + rr] : (need_mask ? mask_of(nzj) : 0.f);
+        xA[l] = nzj;
+        for (int i = l; i < S; i += GL) cA[i] = a.z[(size_t)i * R + rr];
+        __syncthreads();
+        float nzv[NFIX];
+#pragma unroll
+        for (int k = 0; k < NFIX; ++k) nzv[k] = xA[k];
+        int rank = 0;
+#pragma unroll
+        for (int k = 0; k < NFIX; ++k) rank += (nzv[k] < nzj || (nzv[k] == nzj && k < l)) ? 1 : 0;
+        int lo = 0, hi = S;                                     // #old <= nzj (the old list is sorted)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cA[mid] <= nzj) lo = mid + 1; else hi = mid;
+        }
+        zM[rank + lo] = nzj; sM[rank + lo] = nsj; mM[rank + lo] = ntj;
+        for (int i = l; i < S; i += GL) {
+            const float zi = cA[i];
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < NFIX; ++k) c += nzv[k] < zi ? 1 : 0;
+            zM[i + c] = zi;
+            sM[i + c] = a.sdf[(size_t)i * R + rr];
+            if (need_mask || a.msk) mM[i + c] = a.msk ? (float)a.msk[(size_t)i * R + rr] : mask_of(zi);
+        }
+        __syncthreads();
+        S += NFIX;
+        if (live) {
+            const bool z_only = MODE == RM_FINALIZE && !a.merge_all_lists;
+            for (int i = l; i < S; i += GL) {
+                a.z[(size_t)i * R + r] = zM[i];
+                if (!z_only) {
+                    a.sdf[(size_t)i * R + r] = sM[i];
+                    if (a.msk) a.msk[(size_t)i * R + r] = (uint8_t)mM[i];
+                }
+            }
+        }
     }
-};
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (MODE == RM_UPSAMPLE) {
+        // pass 1: section opacities in parallel, then the transmittance / weight scan in the reference's order
+        for (int sct = l; sct + 1 < S; sct += GL) {
+            const float z0 = zM[sct], s0 = sM[sct], z1 = zM[sct + 1], s1 = sM[sct + 1];
+            const float prev_dot = sct > 0 ? (s0 - sM[sct - 1]) / (z0 - zM[sct - 1] + 1e-5f) : 0.f;      // the previous section's dot_raw, recomputed
+            float dot_raw;
+            xA[sct] = upsample_section_alpha(z0, s0, mM[sct], z1, s1, mM[sct + 1], prev_dot, a.inv_s, dot_raw);
+        }
+        __syncthreads();
+        float wsum = 0.f;
+        if (l == 0) {
+            float T = 1.f;
+            for (int sct = 0; sct + 1 < S; ++sct) {
+                const float alpha = xA[sct];
+                const float w = alpha * T + 1e-5f;
+                T = T * (1.f - alpha + 1e-7f);
+                xA[sct] = w;
+                wsum += w;
+            }
+        }
+        wsum = __shfl(wsum, sub * GL);
+        __syncthreads();
+        // pass 2: pdf in parallel, CDF in order, then every new sample searches for itself
+        for (int k = l; k + 1 < S; k += GL) xA[k] = xA[k] / wsum;
+        __syncthreads();
+        if (l == 0) {
+            float c = 0.f;
+            cA[0] = 0.f;
+            for (int k = 1; k < S; ++k) { c = c + xA[k - 1]; cA[k] = c; }
+        }
+        __syncthreads();
+        for (int t0 = 0; t0 < a.n_imp; t0 += GL) {
+            const int t = t0 + l;
+            const bool act = t < a.n_imp;
+            float zn = 0.f, x = 0.f, y = 0.f, w = 0.f;
+            bool in = false;
+            if (act) {
+                const float u = linspace_at(0.5f / (float)a.n_imp, 1.f - 0.5f / (float)a.n_imp, a.n_imp, t);
+                int lo = 0, hi = S;                                 // searchsorted(right = True): first k with cdf[k] > u (k >= 1 since cdf[0] = 0 < u), else S
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (cA[mid] > u) hi = mid; else lo = mid + 1;
+                }
+                const int k = lo;
+                const float cb = cA[k - 1];
+                const float ca = (k == S) ? cb : cA[k];
+                float den = ca - cb;
+                if (den < 1e-5f) den = 1.f;
+                const float tt = (u - cb) / den;
+                const float zlo = zM[k - 1], zhi = zM[k < S ? k : S - 1];
+                zn = zlo + tt * (zhi - zlo);
+                ray_point(a.g, rr, zn, x, y, w);
+                in = mask_at(a.maskvol, a.D, x, y, w) > 0.f;
+                if (live) {
+                    const size_t slot = (size_t)t * R + r;
+                    a.out_z[slot] = zn;
+                    a.out_pts[3 * slot] = x; a.out_pts[3 * slot + 1] = y; a.out_pts[3 * slot + 2] = w;
+                    a.out_sdf[slot] = 100.f;                         // cat_z_vals default outside the mask (:135)
+                    if (a.out_msk) a.out_msk[slot] = in ? 1 : 0;
+                }
+            }
+            const bool valid = act && live && in;
+            const unsigned long long bm = __ballot(valid);
+            if (bm) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(a.count, __popcll(bm));
+                base = __shfl(base, 0);
+                if (valid) a.list[base + __popcll(bm & lt)] = t * R + r;
+            }
+        }
+    } else if (MODE == RM_FINALIZE) {
+        for (int s0 = 0; s0 < S; s0 += GL) {
+            const int smp = s0 + l;
+            const bool act = smp < S && live;
+            bool occ = false;
+            if (act) {
+                const float zc = zM[smp];
+                const float d = (smp + 1 < S) ? zM[smp + 1] - zc : a.sample_dist;
+                const float mz = zc + d * 0.5f;
+                float x, y, w;
+                ray_point(a.g, r, mz, x, y, w);
+                const float m = mask_at(a.maskvol, a.D, x, y, w);
+                const size_t p = (size_t)smp * R + r;
+                a.dists[p] = d; a.mid_z[p] = mz; a.pm[p] = m;
+                a.pts[3 * p] = x; a.pts[3 * p + 1] = y; a.pts[3 * p + 2] = w;
+                occ = m > 0.f;
+                if (!occ || a.defaults_everywhere) {                 // see k_ray_stream
+                    a.o_sdf[p] = 100.f;
+                    a.grad[3 * p] = 0.f; a.grad[3 * p + 1] = 0.f; a.grad[3 * p + 2] = 0.f;
+                    a.rgb[3 * p] = 0.f; a.rgb[3 * p + 1] = 0.f; a.rgb[3 * p + 2] = 0.f;
+                }
+            }
+            const unsigned long long bm = __ballot(occ);
+            if (bm) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(a.count, __popcll(bm));
+                base = __shfl(base, 0);
+                if (occ) a.list[base + __popcll(bm & lt)] = smp * R + r;
+            }
+        }
+    }
+}
+
+// render_core's compositing for small batches, sixteen lanes per ray: per-sample opacities and products in parallel, ONE lane runs the ordered
+// accumulation (transmittance, weight / colour / depth sums, then the depth variance) out of LDS, the per-sample outputs are written in parallel.
+constexpr int COMP_ARRAYS = 9;
+__global__ __launch_bounds__(64) void k_ray_composite_group(RayGeom g, int S, const float* __restrict__ mid_z, const float* __restrict__ dists,
+                                                            const float* __restrict__ pm, const float* __restrict__ sdf,
+                                                            const float* __restrict__ grad, const float* __restrict__ rgb,
+                                                            const uint8_t* __restrict__ nviews, float inv_s, float air, float bg, CompositeOut o) {
+    extern __shared__ float lds[];
+    const int R = g.R, lane = threadIdx.x, sub = lane >> 4, l = lane & 15;
+    const int r = blockIdx.x * GR + sub;
+    const bool live = r < R;
+    const int rr = live ? r : R - 1;
+    float* L[COMP_ARRAYS];
+#pragma unroll
+    for (int k = 0; k < COMP_ARRAYS; ++k) L[k] = lds + (size_t)(k * GR + sub) * S;
+    float *aL = L[0], *c0L = L[1], *c1L = L[2], *c2L = L[3], *zL = L[4], *gL = L[5], *mL = L[6], *nL = L[7], *wL = L[8];
+    const float dx = g.rays_d[3 * rr], dy = g.rays_d[3 * rr + 1], dz = g.rays_d[3 * rr + 2];
+    for (int smp = l; smp < S; smp += GL) {
+        const size_t p = (size_t)smp * R + rr;
+        const float m = pm[p];
+        const float gx = grad[3 * p], gy = grad[3 * p + 1], gz = grad[3 * p + 2];
+        float pc;
+        aL[smp] = composite_sample_alpha(dx, dy, dz, gx, gy, gz, m, dists[p], sdf[p], inv_s, air, pc);
+        if (live) o.cdf[p] = pc;
+        c0L[smp] = rgb[3 * p]; c1L[smp] = rgb[3 * p + 1]; c2L[smp] = rgb[3 * p + 2];
+        zL[smp] = mid_z[p];
+        const float gn = sqrtf(gx * gx + gy * gy + gz * gz) - 1.f;
+        gL[smp] = m * (gn * gn);
+        mL[smp] = m;
+        nL[smp] = nviews[p] >= 2 ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (l == 0 && live) {
+        float T = 1.f, wsum = 0.f, wmax = 0.f, asum = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, ge = 0.f, gm = 0.f;
+        int n_seen = 0;
+        for (int smp = 0; smp < S; ++smp) {
+            const float alpha = aL[smp];
+            const float w = alpha * T;
+            T = T * (1.f - alpha + 1e-7f);
+            wL[smp] = w;
+            wsum += w; wmax = fmaxf(wmax, w); asum += alpha;
+            c0 += c0L[smp] * w; c1 += c1L[smp] * w; c2 += c2L[smp] * w;
+            dep += zL[smp] * w;
+            ge += gL[smp]; gm += mL[smp];
+            n_seen += nL[smp] > 0.f ? 1 : 0;
+        }
+        const float bgc = bg * (1.f - wsum);
+        o.color[3 * r] = c0 + bgc; o.color[3 * r + 1] = c1 + bgc; o.color[3 * r + 2] = c2 + bgc;
+        o.depth[r] = dep;
+        o.weights_sum[r] = wsum; o.weights_max[r] = wmax; o.alpha_sum[r] = asum;
+        o.grad_err[2 * r] = ge; o.grad_err[2 * r + 1] = gm;
+        o.color_mask[r] = n_seen > 8 ? 1 : 0;
+        float dv = 0.f;
+        for (int smp = 0; smp < S; ++smp) {
+            const float d = zL[smp] - dep;
+            dv += d * d * wL[smp];
+        }
+        o.depth_var[r] = dv;
+    }
+    __syncthreads();
+    if (live)
+        for (int smp = l; smp < S; smp += GL) o.weights[(size_t)smp * R + r] = wL[smp];
+}
+
+// cat_z_vals for a block size other than NFIX: the plain per-ray merge on the global lists (render_math.h merge_ray), occupancy bytes along
 __global__ __launch_bounds__(64) void k_ray_merge_any(int R, float* z, float* sdf, uint8_t* msk, int S, const float* new_z, const float* new_sdf,
                                                       const uint8_t* new_msk, int n_new) {
     const int r = blockIdx.x * 64 + threadIdx.x;
@@ -357,8 +592,8 @@ int o2345_ray_coarse(const float* rays_o, const float* rays_d, int R, float near
     return o2345_ray_coarse_jitter(rays_o, rays_d, R, near, far, S, nullptr, z, pts, stream);
 }
 
-// One launch of k_ray_round.  A merge of exactly NFIX samples runs fused (in LDS); any other block size is merged on the global lists first.
-static int ray_round_launch(int mode, RoundArgs a, void* stream) {
+// One round launch.  A merge of exactly NFIX samples runs fused; any other block size is merged on the global lists first (k_ray_merge_any).
+static int ray_round_launch(int mode, RoundArgs a, float* wbuf /* [rows][R] scratch of the streaming up-sample kernel, or null */, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int R = a.g.R;
     if (a.n_new > 0 && a.n_new != NFIX) {
@@ -368,25 +603,34 @@ static int ray_round_launch(int mode, RoundArgs a, void* stream) {
         if (mode == RM_MERGE_ONLY) return check_launch("ray_merge");
     }
     const bool merge = a.n_new > 0;
-    const int rows = a.S + (merge ? NFIX : 0) + (mode == RM_UPSAMPLE ? a.n_imp : 0);
-    const size_t lds = (size_t)rows * RAY_LDS_ROW_BYTES;
-    O2345_REQUIRE(lds <= 160 * 1024, "ray kernels: %d list rows per ray do not fit the 160 KB of LDS (at most 284)", rows);
-    const dim3 grid(cdiv(R, RT)), block(RT);
-#define O2345_ROUND(M, MG)                                                        \
-    {                                                                             \
-        O2345_ENSURE_LDS((k_ray_round<M, MG>), 160 * 1024);                       \
-        hipLaunchKernelGGL((k_ray_round<M, MG>), grid, block, lds, s, a);         \
+    // large batches: streaming kernels (one lane per ray, full occupancy); small ones: sixteen lanes per ray (csrc/common.h knobs(): O2345_RAY_STREAM_MIN)
+    const bool streaming = (long long)R >= knobs().ray_stream_min && (mode != RM_UPSAMPLE || wbuf != nullptr);
+    if (streaming) {
+        const dim3 grid(cdiv(R, 256)), block(256);
+#define O2345_STREAM(M, MG) hipLaunchKernelGGL((k_ray_stream<M, MG>), grid, block, 0, s, a, wbuf);
+        if (mode == RM_UPSAMPLE) { if (merge) O2345_STREAM(RM_UPSAMPLE, true) else O2345_STREAM(RM_UPSAMPLE, false) }
+        else if (mode == RM_FINALIZE) { if (merge) O2345_STREAM(RM_FINALIZE, true) else O2345_STREAM(RM_FINALIZE, false) }
+        else if (merge) O2345_STREAM(RM_MERGE_ONLY, true)
+#undef O2345_STREAM
+        return check_launch("ray_round (streaming)");
     }
-    if (mode == RM_UPSAMPLE) { if (merge) O2345_ROUND(RM_UPSAMPLE, true) else O2345_ROUND(RM_UPSAMPLE, false) }
-    else if (mode == RM_FINALIZE) { if (merge) O2345_ROUND(RM_FINALIZE, true) else O2345_ROUND(RM_FINALIZE, false) }
-    else if (merge) O2345_ROUND(RM_MERGE_ONLY, true)
-#undef O2345_ROUND
+    {
+        const int rows = a.S + (merge ? NFIX : 0);
+        const size_t lds = group_lds_bytes(rows);
+        O2345_REQUIRE(lds <= 64 * 1024, "ray kernels: %d list rows per ray (at most 600)", rows);
+        const dim3 grid(cdiv(R, GR)), block(64);
+#define O2345_GROUP(M, MG) hipLaunchKernelGGL((k_ray_group<M, MG>), grid, block, lds, s, a);
+        if (mode == RM_UPSAMPLE) { if (merge) O2345_GROUP(RM_UPSAMPLE, true) else O2345_GROUP(RM_UPSAMPLE, false) }
+        else if (mode == RM_FINALIZE) { if (merge) O2345_GROUP(RM_FINALIZE, true) else O2345_GROUP(RM_FINALIZE, false) }
+        else if (merge) O2345_GROUP(RM_MERGE_ONLY, true)
+#undef O2345_GROUP
+    }
     return check_launch("ray_round");
 }
 
 // ---- stage entry points (used by the parity tests; the orchestrator below launches the same kernel with the merge fused in) -----------------
 int o2345_ray_upsample(const float* rays_o, const float* rays_d, int R, const float* z, const float* sdf, int S, float inv_s,
-                       const float* maskvol, int D, int n_imp, float* new_z, float* new_pts, float* new_sdf,
+                       const float* maskvol, int D, float* wbuf, int n_imp, float* new_z, float* new_pts, float* new_sdf,
                        int32_t* list, int32_t* count_dev, void* stream) {
     O2345_REQUIRE(rays_o && rays_d && z && sdf && maskvol && new_z && new_pts && new_sdf && list && count_dev, "ray_upsample: null pointer");
     O2345_REQUIRE(n_imp >= 1 && n_imp <= 256 && S >= 2 && R > 0, "ray_upsample: 1..256 new samples per call, at least 2 samples per ray (got %d, %d)", n_imp, S);
@@ -397,7 +641,7 @@ int o2345_ray_upsample(const float* rays_o, const float* rays_d, int R, const fl
     a.z = const_cast<float*>(z); a.sdf = const_cast<float*>(sdf); a.S = S;          // read-only without a merge
     a.maskvol = maskvol; a.D = D; a.inv_s = inv_s; a.n_imp = n_imp;
     a.out_z = new_z; a.out_pts = new_pts; a.out_sdf = new_sdf; a.list = list; a.count = count_dev;
-    int rc = ray_round_launch(RM_UPSAMPLE, a, stream);
+    int rc = ray_round_launch(RM_UPSAMPLE, a, wbuf, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(k_quirk_min2, dim3(1), dim3(1), 0, s, count_dev);
     return check_launch("ray_upsample");
@@ -408,7 +652,7 @@ int o2345_ray_merge(int R, float* z, float* sdf, int S, float* new_z, float* new
     RoundArgs a{};
     a.g = RayGeom{nullptr, nullptr, R};
     a.z = z; a.sdf = sdf; a.S = S; a.new_z = new_z; a.new_sdf = new_sdf; a.n_new = n_new;
-    return ray_round_launch(RM_MERGE_ONLY, a, stream);
+    return ray_round_launch(RM_MERGE_ONLY, a, nullptr, stream);
 }
 
 int o2345_ray_finalize(const float* rays_o, const float* rays_d, int R, const float* z, int S, float sample_dist,
@@ -423,7 +667,7 @@ int o2345_ray_finalize(const float* rays_o, const float* rays_d, int R, const fl
     a.maskvol = maskvol; a.D = D; a.sample_dist = sample_dist;
     a.mid_z = mid_z; a.dists = dists; a.pts = pts; a.pm = pm; a.o_sdf = sdf; a.grad = grad; a.rgb = rgb; a.defaults_everywhere = 1;
     a.list = list; a.count = count_dev;
-    return ray_round_launch(RM_FINALIZE, a, stream);
+    return ray_round_launch(RM_FINALIZE, a, nullptr, stream);
 }
 
 int o2345_ray_composite(const float* rays_o, const float* rays_d, int R, int S, const float* mid_z, const float* dists,
@@ -435,17 +679,22 @@ int o2345_ray_composite(const float* rays_o, const float* rays_d, int R, int S, 
                   weights_sum && weights_max && depth_var && alpha_sum && grad_err && color_mask, "ray_composite: null pointer");
     RayGeom g{rays_o, rays_d, R};
     CompositeOut o{color, depth, weights, cdf, weights_sum, weights_max, depth_var, alpha_sum, grad_err, color_mask};
-    hipLaunchKernelGGL(k_ray_composite, dim3(cdiv(R, 64)), dim3(64), 0, (hipStream_t)stream, g, S, mid_z, dists, pm, sdf, grad, rgb, nviews, inv_s, alpha_inter_ratio, background, o);
+    if ((long long)R >= knobs().ray_stream_min || (size_t)COMP_ARRAYS * GR * S * sizeof(float) > 64 * 1024)
+        hipLaunchKernelGGL(k_ray_composite, dim3(cdiv(R, 64)), dim3(64), 0, (hipStream_t)stream, g, S, mid_z, dists, pm, sdf, grad, rgb, nviews, inv_s, alpha_inter_ratio, background, o);
+    else      // small batches: sixteen lanes per ray
+        hipLaunchKernelGGL(k_ray_composite_group, dim3(cdiv(R, GR)), dim3(64), (size_t)COMP_ARRAYS * GR * S * sizeof(float), (hipStream_t)stream, g, S, mid_z, dists, pm, sdf,
+                           grad, rgb, nviews, inv_s, alpha_inter_ratio, background, o);
     return check_launch("ray_composite");
 }
 
 // ---- the whole render() call -----------------------------------------------------------------------------------------
 // Workspace layout (floats unless noted), S = n_samples + n_importance, NI = n_importance / 4, R rays:
-//   z[S*R] sdf[S*R] new_z[NI*R] new_sdf[NI*R] pts[3*S*R] list[S*R ints] count[16 ints] msk[S*R bytes] new_msk[NI*R bytes]
+//   z[S*R] sdf[S*R] new_z[NI*R] new_sdf[NI*R] pts[3*S*R] list[S*R ints] count[64 ints] msk[S*R bytes] new_msk[NI*R bytes] wbuf[S*R] (streaming kernels only)
 //   ... and, when the list is sorted: sorted list[S*R ints] + the workspace of o2345_list_sort_by_visibility (csrc/list_sort.hip)
 static size_t render_core_workspace_bytes(int R, int n_samples, int n_importance) {
     const size_t S = (size_t)n_samples + n_importance, NI = (size_t)(n_importance / 4 > 0 ? n_importance / 4 : 1);
-    const size_t bytes = ((S * 2 + NI * 2 + 3 * S + S) * (size_t)R + 64) * 4 + (S + NI) * (size_t)R;
+    size_t bytes = ((S * 2 + NI * 2 + 3 * S + S) * (size_t)R + 64) * 4 + ((S + NI) * (size_t)R + 3) / 4 * 4;
+    if ((long long)R >= knobs().ray_stream_min) bytes += S * (size_t)R * 4;
     return (bytes + 255) / 256 * 256;
 }
 // The occupied-point list is grouped by view-visibility signature only where that pays: the sort is 4 launches per 8 views and costs 0.1 - 0.25 ms
@@ -481,6 +730,7 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     int* count = list + S * RR;                  // [0..3]: new points of the four up-sampling rounds, [4]: occupied mid-points
     uint8_t* msk = (uint8_t*)(count + 64);       // occupancy of every sample point, carried with the lists
     uint8_t* new_msk = msk + S * RR;
+    float* wbuf = (long long)R >= knobs().ray_stream_min ? (float*)(msk + ((S + NI) * RR + 3) / 4 * 4) : nullptr;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     O2345_REQUIRE(io->sdf_mode == 0 || io->sdf_mode == 2, "render_rays: SDF mode %d (0 = fp32, 2 = split-f16; the bf16 mode 1 was removed)", io->sdf_mode);
@@ -502,7 +752,7 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     int cur = NS;
     for (int i = 0; i < 4; ++i) {
         ra.S = cur; ra.n_new = i ? (int)NI : 0; ra.inv_s = 64.f * (float)(1 << i); ra.count = count + i;
-        if ((rc = ray_round_launch(RM_UPSAMPLE, ra, stream))) return rc;
+        if ((rc = ray_round_launch(RM_UPSAMPLE, ra, wbuf, stream))) return rc;
         cur += ra.n_new;
         hipLaunchKernelGGL(k_quirk_min2, dim3(1), dim3(1), 0, s, count + i);
         if ((rc = sdf_eval(0, pts, list, count + i, 0, new_sdf, nullptr))) return rc;
@@ -514,7 +764,7 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     // the last cat_z_vals fused with render_core's head
     ra.S = cur; ra.n_new = (int)NI; ra.count = count; ra.sample_dist = sample_dist;
     ra.mid_z = io->mid_z; ra.dists = io->dists; ra.pts = fpts; ra.pm = io->pm; ra.o_sdf = io->sdf; ra.grad = io->grad; ra.rgb = io->rgb; ra.defaults_everywhere = 0;
-    if ((rc = ray_round_launch(RM_FINALIZE, ra, stream))) return rc;
+    if ((rc = ray_round_launch(RM_FINALIZE, ra, nullptr, stream))) return rc;
     hipLaunchKernelGGL(k_quirk_first100, dim3(1), dim3(128), 0, s, count, list, R, (int)S);
     // the list grouped by view-visibility signature (stable): the colour kernel then skips every (tile, view) pair in which no point sees the view instead of
     // 3/4 of them -- 40.0 -> 36.1 ms at 8 views, bit-identical results (csrc/list_sort.hip); only for lists long enough to pay for it (render_sorts_list)

@@ -54,51 +54,92 @@ struct GlobalRay {
     O2345_HD void out(int t, float v) { out_[(size_t)t * R + r] = v; }
 };
 
+// One section [s, s + 1] of up_sample (:89-107): the opacity alpha_s from the two samples' depth / SDF / occupancy and the slope of the PREVIOUS
+// section (prev_dot; 0 for the first).  dot_raw_out = this section's slope (the next section's prev_dot).  Independent of the running transmittance.
+O2345_HD float upsample_section_alpha(float z0, float s0, float m0, float z1, float s1, float m1, float prev_dot, float inv_s, float& dot_raw_out) {
+    const float pm = m0 * m1;
+    const float mid = (s0 + s1) * 0.5f;
+    const float dot_raw = (s1 - s0) / (z1 - z0 + 1e-5f);
+    float dot = fminf(prev_dot, dot_raw);
+    dot = fminf(fmaxf(dot, -10.f), 0.f) * pm;
+    dot_raw_out = dot_raw;
+    const float dist = z1 - z0;
+    const float pe = mid - dot * dist * 0.5f, ne = mid + dot * dist * 0.5f;
+    const float pc = sigmoidf_(pe * inv_s), nc = sigmoidf_(ne * inv_s);
+    return pm * ((pc - nc + 1e-5f) / (pc + 1e-5f));
+}
+
 // up_sample + sample_pdf(det=True): from S sorted samples (z, sdf) of one ray produce n_imp new z values (a.out(t, z_new), t < n_imp).
+// STREAMING form: both passes touch the lists at statically known, ascending rows, a block of CB rows is requested before any of it is used -- with
+// the global-memory accessor every block is ONE round trip with 3 x CB loads in flight (round 3 paid a dependent trip per sample), and no pass indexes
+// a list at a data-dependent position.  The arithmetic, operation by operation and in the same order, is the reference's:
+//   pass 1 (:84-107)  section weights w_s = alpha_s * T_s + 1e-5 with the running transmittance T, and their sum;
+//   pass 2 (render_utils.py:24-50)  cdf_k = cdf_{k-1} + w_{k-1} / sum; for the ascending u_t the search index k only moves forward, so the inverse
+//           CDF is a single walk over k that emits every u_t whose interval closes at k (searchsorted(right = True): first k with cdf_k > u_t, or S).
 template <class A>
 O2345_HD void upsample_core(A& a, int S, float inv_s, int n_imp) {
+    constexpr int CB = 8;
     float z0 = a.z(0), s0 = a.sdf(0);
     float m0 = a.msk(0, z0);
     float prev_dot = 0.f, T = 1.f, wsum = 0.f;
-    for (int s = 0; s + 1 < S; ++s) {
-        const float z1 = a.z(s + 1), s1 = a.sdf(s + 1);
-        const float m1 = a.msk(s + 1, z1);
-        const float pm = m0 * m1;
-        const float mid = (s0 + s1) * 0.5f;
-        const float dot_raw = (s1 - s0) / (z1 - z0 + 1e-5f);
-        float dot = fminf(prev_dot, dot_raw);
-        dot = fminf(fmaxf(dot, -10.f), 0.f) * pm;
-        prev_dot = dot_raw;
-        const float dist = z1 - z0;
-        const float pe = mid - dot * dist * 0.5f, ne = mid + dot * dist * 0.5f;
-        const float pc = sigmoidf_(pe * inv_s), nc = sigmoidf_(ne * inv_s);
-        const float alpha = pm * ((pc - nc + 1e-5f) / (pc + 1e-5f));
-        const float w = alpha * T + 1e-5f;            // sample_pdf: weights + 1e-5
-        T = T * (1.f - alpha + 1e-7f);
-        a.set_w(s, w);
-        wsum += w;
-        z0 = z1; s0 = s1; m0 = m1;
-    }
-    // inverse CDF, u ascending -> one forward walk.  cdf[0] = 0, cdf[k] = cdf[k-1] + pdf[k-1]  (k < S)
-    int k = 0;                // cdf index of c_hi
-    float c_lo = 0.f, c_hi = 0.f;   // cdf[k-1], cdf[k]
-    for (int t = 0; t < n_imp; ++t) {
-        const float u = linspace_at(0.5f / (float)n_imp, 1.f - 0.5f / (float)n_imp, n_imp, t);
-        // searchsorted(right=True): first index with cdf[idx] > u
-        while (k < S && !(c_hi > u)) {
-            ++k;
-            c_lo = c_hi;
-            if (k < S) c_hi = c_hi + a.w(k - 1) / wsum;
+    for (int sb = 0; sb + 1 < S; sb += CB) {
+        float zb[CB], sv[CB], mb[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            const int i = sb + 1 + k < S ? sb + 1 + k : S - 1;          // the tail re-reads the last row (never used)
+            zb[k] = a.z(i); sv[k] = a.sdf(i);
         }
-        // ind = k (may be S).  below = max(0, ind-1), above = min(S-1, ind)
-        int below = k - 1 < 0 ? 0 : k - 1, above = k > S - 1 ? S - 1 : k;
-        const float cb = (k == 0) ? c_hi : c_lo;
-        const float ca = (above == below) ? cb : c_hi;
-        float den = ca - cb;
-        if (den < 1e-5f) den = 1.f;
-        const float tt = (u - cb) / den;
-        const float zb = a.z(below), za = a.z(above);
-        a.out(t, zb + tt * (za - zb));
+#pragma unroll
+        for (int k = 0; k < CB; ++k) mb[k] = a.msk(sb + 1 + k < S ? sb + 1 + k : S - 1, zb[k]);
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            if (sb + 1 + k < S) {
+                const float z1 = zb[k], s1 = sv[k], m1 = mb[k];
+                float dot_raw;
+                const float alpha = upsample_section_alpha(z0, s0, m0, z1, s1, m1, prev_dot, inv_s, dot_raw);
+                prev_dot = dot_raw;
+                const float w = alpha * T + 1e-5f;            // sample_pdf: weights + 1e-5
+                T = T * (1.f - alpha + 1e-7f);
+                a.set_w(sb + k, w);
+                wsum += w;
+                z0 = z1; s0 = s1; m0 = m1;
+            }
+        }
+    }
+    // inverse CDF.  State after advancing to k: c_lo = cdf[k-1], c_hi = cdf[k] (cdf[0] = 0; k = S: nothing is added).  u_0 > 0 = cdf[0], so every
+    // sample is emitted at some k >= 1 with below = k - 1, above = min(k, S - 1).
+    int t = 0;
+    float c_lo = 0.f, c_hi = 0.f;
+    float u = linspace_at(0.5f / (float)n_imp, 1.f - 0.5f / (float)n_imp, n_imp, 0);
+    float zlo = a.z(0);                                       // z[k - 1]
+    for (int kb = 1; kb <= S && t < n_imp; kb += CB) {
+        float wb[CB], zb[CB];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            const int k = kb + j;
+            wb[j] = a.w(k - 1 < S - 1 ? k - 1 : S - 2 >= 0 ? S - 2 : 0);      // w[k - 1], defined for k < S
+            zb[j] = a.z(k < S ? k : S - 1);                                    // z[above]
+        }
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            const int k = kb + j;
+            if (k <= S) {
+                c_lo = c_hi;
+                if (k < S) c_hi = c_hi + wb[j] / wsum;
+                const float zhi = zb[j];
+                while (t < n_imp && (k == S || c_hi > u)) {
+                    const float cb = c_lo;
+                    const float ca = (k == S) ? cb : c_hi;                     // above == below only when k == S
+                    float den = ca - cb;
+                    if (den < 1e-5f) den = 1.f;
+                    const float tt = (u - cb) / den;
+                    a.out(t, zlo + tt * (zhi - zlo));
+                    ++t;
+                    u = linspace_at(0.5f / (float)n_imp, 1.f - 0.5f / (float)n_imp, n_imp, t < n_imp ? t : n_imp - 1);
+                }
+                zlo = zhi;
+            }
+        }
     }
 }
 
@@ -156,12 +197,26 @@ O2345_HD void merge_core_fixed(A& a, int S, float (&nz)[N], float (&ns)[N], unsi
     int cnt[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) cnt[j] = 0;
-    for (int i = S - 1; i >= 0; --i) {
-        const float zi = a.z(i);
-        int c = 0;
+    constexpr int CB = 8;                       // rows are requested CB at a time, descending (writes of a block go to rows >= its lowest row: never to a row not yet read)
+    for (int ib = S - 1; ib >= 0; ib -= CB) {
+        float zb[CB], sb[CB];
+        unsigned tb[CB];
 #pragma unroll
-        for (int j = 0; j < N; ++j) { c += nz[j] < zi ? 1 : 0; cnt[j] += zi <= nz[j] ? 1 : 0; }
-        if (c) a.put(i + c, zi, a.sdf(i), a.tag(i));
+        for (int k = 0; k < CB; ++k) {
+            const int i = ib - k >= 0 ? ib - k : 0;
+            zb[k] = a.z(i); sb[k] = a.sdf(i); tb[k] = a.tag(i);
+        }
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            const int i = ib - k;
+            if (i >= 0) {
+                const float zi = zb[k];
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) { c += nz[j] < zi ? 1 : 0; cnt[j] += zi <= nz[j] ? 1 : 0; }
+                if (c) a.put(i + c, zi, sb[k], tb[k]);
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) a.put(j + cnt[j], nz[j], ns[j], nt[j]);
@@ -204,6 +259,20 @@ struct CompositeOut {
     uint8_t* color_mask;  // [R]
 };
 
+// One sample of render_core's compositing (:340-372): opacity alpha and the sigmoid pc (the returned "cdf") from the sample's SDF, gradient, section
+// length and occupancy; independent of the running transmittance.
+O2345_HD float composite_sample_alpha(float dx, float dy, float dz, float gx, float gy, float gz, float m, float dist, float sv, float inv_s,
+                                      float alpha_inter_ratio, float& pc_out) {
+    const float tdot = dx * gx + dy * gy + dz * gz;
+    float icos = -(fmaxf(-tdot * 0.5f + 0.5f, 0.f) * (1.f - alpha_inter_ratio) + fmaxf(-tdot, 0.f) * alpha_inter_ratio);
+    icos = icos * m;
+    const float half = fminf(fmaxf(icos, -10.f), 10.f) * dist * 0.5f;
+    const float pc = sigmoidf_((sv - half) * inv_s), nc = sigmoidf_((sv + half) * inv_s);
+    float alpha = (pc - nc + 1e-5f) / (pc + 1e-5f);
+    pc_out = pc;
+    return fminf(fmaxf(alpha, 0.f), 1.f) * m;
+}
+
 O2345_HD void composite_ray(const RayGeom& g, int r, int S, const float* __restrict__ mid_z,
                             const float* __restrict__ dists, const float* __restrict__ pm, const float* __restrict__ sdf,
                             const float* __restrict__ grad /*[S*R,3]*/, const float* __restrict__ rgb /*[S*R,3]*/,
@@ -235,14 +304,8 @@ O2345_HD void composite_ray(const RayGeom& g, int r, int S, const float* __restr
                 const size_t p = (size_t)(sb + k) * R + r;
                 const float m = bm[k];
                 const float gx = bg[k][0], gy = bg[k][1], gz = bg[k][2];
-                const float tdot = dx * gx + dy * gy + dz * gz;
-                float icos = -(fmaxf(-tdot * 0.5f + 0.5f, 0.f) * (1.f - alpha_inter_ratio) + fmaxf(-tdot, 0.f) * alpha_inter_ratio);
-                icos = icos * m;
-                const float half = fminf(fmaxf(icos, -10.f), 10.f) * bd[k] * 0.5f;
-                const float sv = bs[k];
-                const float pc = sigmoidf_((sv - half) * inv_s), nc = sigmoidf_((sv + half) * inv_s);
-                float alpha = (pc - nc + 1e-5f) / (pc + 1e-5f);
-                alpha = fminf(fmaxf(alpha, 0.f), 1.f) * m;
+                float pc;
+                const float alpha = composite_sample_alpha(dx, dy, dz, gx, gy, gz, m, bd[k], bs[k], inv_s, alpha_inter_ratio, pc);
                 const float w = alpha * T;
                 T = T * (1.f - alpha + 1e-7f);
                 wout[p] = w;

@@ -623,17 +623,19 @@ def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64,
 
 
 @_on_device
-def ray_upsample(rays_o, rays_d, z, sdf, inv_s, maskvol, D, n_imp):
+def ray_upsample(rays_o, rays_d, z, sdf, inv_s, maskvol, D, n_imp, streaming=None):
     """Stage entry point of the hierarchical sampler (up_sample + sample_pdf, sparse_neus_renderer.py:73-115, render_utils.py:8-51):
     z, sdf SAMPLE-MAJOR [S,R] -> (new_z [n_imp,R], new_pts [n_imp,R,3], valid-point list int32 [<= n_imp*R] of slots t*R + r)."""
     S, R = z.shape
     dev = z.device
+    # streaming=None: scratch is handed over and the library picks the kernel by R (O2345_RAY_STREAM_MIN); False: no scratch -> the LDS-staged kernel
+    wbuf = None if streaming is False else torch.empty(S, R, dtype=torch.float32, device=dev)
     new_z = torch.empty(n_imp, R, dtype=torch.float32, device=dev)
     new_pts = torch.empty(n_imp, R, 3, dtype=torch.float32, device=dev)
     new_sdf = torch.empty(n_imp, R, dtype=torch.float32, device=dev)
     lst = torch.empty(n_imp * R, dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-    check(_lib.lib().o2345_ray_upsample(_p(rays_o), _p(rays_d), R, _p(z), _p(sdf), S, float(inv_s), _p(maskvol), int(D), int(n_imp),
+    check(_lib.lib().o2345_ray_upsample(_p(rays_o), _p(rays_d), R, _p(z), _p(sdf), S, float(inv_s), _p(maskvol), int(D), _p(wbuf), int(n_imp),
                                         _p(new_z), _p(new_pts), _p(new_sdf), _p(lst, torch.int32), _p(cnt, torch.int32), _stream()), "ray_upsample")
     return new_z, new_pts, lst[:int(cnt.item())]
 

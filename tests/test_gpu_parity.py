@@ -689,3 +689,37 @@ def test_list_sort_by_visibility(pkg, ops, V):
         ref |= ((pr[:, 0] > 0) & (pr[:, 0] < 255 * z) & (pr[:, 1] > 0) & (pr[:, 1] < 255 * z)).long() << v
     assert float((ref != k).float().mean()) < 1e-3
     assert int(torch.unique(k).numel()) > 3
+
+
+def test_ray_kernels_streaming_and_lds_forms_are_bit_identical(dev, ops, lib_instance):
+    """csrc/render.hip has two forms of every sampler round and of the compositing kernel: sixteen lanes per ray (small batches, e.g. the 512-ray chunks of
+    the reference's val loop: only the two scans of a round are serial) and streaming (one lane per ray on the global lists; large batches), selected by
+    the ray count (O2345_RAY_STREAM_MIN).  They share render_math.h and must agree BIT FOR BIT: a whole render call in both forms (every output), and the
+    up-sampling stage entry on 5,000 rays."""
+    s = small_scene()
+    d = dev_scene(s, dev, ops)
+    sc = s["sc"]
+    ro, rd = rays_for(s, 333, seed=11, center=False)
+    near, far = float(sc["query_near_far"][0]), float(sc["query_near_far"][1])
+    qcam = torch.from_numpy(sc["query_c2w"][:3, 3].copy()).to(dev)
+    scene = {k: d[k] for k in ("sdf_blob", "color_mfma_blob", "color_x3_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos")}
+    t_rand = torch.rand(333, 64, generator=torch.Generator().manual_seed(3)).to(dev)
+    outs = {}
+    for name, thr in (("group", "1000000000"), ("stream", "0")):
+        assert ("ray_stream_min=" + thr).encode() in lib_instance({"O2345_RAY_STREAM_MIN": thr}).o2345_knobs()
+        outs[name] = ops.render_rays(scene, torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev), near, far, 64, 64, 7.4, 0.5, 1.0, qcam, want_z=True,
+                                     t_rand=t_rand, want_scalars=True)
+    for k, v in outs["group"].items():
+        assert torch.equal(v, outs["stream"][k]), k
+    assert float(outs["group"]["weights_sum"].max()) > 0.5
+    # stage entry, default library: 5,000 rays take the streaming kernel when scratch is handed over, the sixteen-lane kernel without
+    lib_instance({})
+    R, S = 5000, 80
+    g = torch.Generator().manual_seed(5)
+    sel = torch.randint(0, ro.shape[0], (R,), generator=g)
+    tro, trd = torch.from_numpy(ro)[sel].contiguous().to(dev), torch.from_numpy(rd)[sel].contiguous().to(dev)
+    z = torch.sort(torch.rand(S, R, generator=g) * (far - near) + near, 0).values.contiguous().to(dev)
+    sdf = ((1.4 - z.cpu()) * (0.5 + torch.rand(S, R, generator=g))).contiguous().to(dev)
+    a = ops.ray_upsample(tro, trd, z, sdf, 256.0, d["maskvol"].reshape(-1), s["D"], 16)
+    b = ops.ray_upsample(tro, trd, z, sdf, 256.0, d["maskvol"].reshape(-1), s["D"], 16, streaming=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(torch.sort(a[2]).values, torch.sort(b[2]).values) and a[2].numel() > 100
