@@ -428,6 +428,27 @@ def c3_block(dev, wt, inp, a, rank, world):
             "scenes": n_scenes, "scenes_per_s": n_scenes / dt, "rays_per_s": n_scenes * n_rays / dt, "seconds": dt, "h2d_bytes_per_scene": int(host[0].numel() * 4)}
 
 
+def dropin_block(dev):
+    """The reference's OWN timing brackets (trainer_generic.py:1072-1094: "export mesh time", "val_step time") taken on the drop-in surface -- the recon/*
+    mirrors + shims driven in the unchanged trainer's call order with its host round trips (tools/dropin_bench.py), at the reference configuration
+    (V = 32, 96^3, 256^3 grid, 512-ray chunks).  ``warm``: in this process; ``fresh_process`` x 2: `python tools/dropin_bench.py --cold` twice -- run.py
+    starts one process per shape (run.py:61-67), so the first bracket of a fresh process IS the product's latency; the first of the two also fills the
+    on-disk cache of packed weights (weights.cached_pack), the second is what every later process on the machine sees."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dropin_bench as DB
+    out = {"warm": DB.run(dev, reps=5)}
+    keep = ("import_torch_ms", "hip_context_ms", "load_library_ms", "construct_networks_ms", "export_mesh_first_call_ms", "export_mesh_first_call_stages_ms",
+            "val_step_first_call_ms", "export_mesh_warm_ms_median", "val_step_warm_ms_median", "process_total_s", "cpu_threads", "vertices", "error", "rc")
+    for name in ("fresh_process_1", "fresh_process_2"):
+        d = DB.cold_subprocess()
+        out[name] = {k: d[k] for k in keep if k in d}
+    w = out["warm"]
+    out["summary"] = {"export_mesh_warm_ms": w["export_mesh_warm_ms_median"], "export_mesh_fresh_process_ms": out["fresh_process_2"].get("export_mesh_first_call_ms"),
+                      "val_step_warm_ms": w.get("val_step_warm_ms_median"), "reference_published_export_mesh_ms": 2488.7,
+                      "speedup_vs_published_fresh_process": (2488.7 / out["fresh_process_2"]["export_mesh_first_call_ms"]) if out["fresh_process_2"].get("export_mesh_first_call_ms") else None}
+    return out
+
+
 def reexec_under_torchrun(n):
     """`python bench.py --gpus N` invoked bare: start N ranks on this node (one per GPU) through torch.distributed.run."""
     import socket
@@ -451,7 +472,8 @@ def main():
     ap.add_argument("--ray-chunk", type=int, default=1 << 18)
     ap.add_argument("--cpu-rays", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--quick", action="store_true", help="only the contract's line (no c3 / ref_config / config5 / fp32 blocks)")
+    ap.add_argument("--quick", action="store_true", help="only the contract's line (no c3 / ref_config / config5 / fp32 / dropin blocks)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the `dropin` block (the reference's own timing brackets on the drop-in surface, warm and in fresh processes)")
     ap.add_argument("--same-scene", action="store_true", help="re-reconstruct one scene every step (round-1 behaviour; A/B knob)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for the CPU plumbing test)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous + sharding only, no GPU work (CPU plumbing test)")
@@ -608,6 +630,10 @@ def main():
             result["ref_config"] = ref_config_block(dev, wt)
             torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
             result["config5"] = config5_block(dev, wt, a)
+            wt = None
+            torch.cuda.empty_cache()
+            if not a.no_dropin:
+                result["dropin"] = dropin_block(dev)
         print(json.dumps(result))
     sharding.shutdown()
 

@@ -15,9 +15,44 @@ void set_error(const char* fmt, ...) {
 
 #include <stddef.h>
 
+namespace o2345 {
+int preload_costvol();
+int preload_sparse();
+int preload_sparse_mfma();
+int preload_sdf_mlp();
+int preload_sdf_mlp_x3();
+int preload_render();
+int preload_list_sort();
+int preload_color_maps();
+int preload_color_pts();
+int preload_mcubes();
+int preload_mesh_pack();
+int preload_featmaps();
+int preload_convnet();
+}
+
 extern "C" {
 const char* o2345_last_error(void) { return o2345::g_err; }
 int o2345_version(void) { return 200; }     // 2.0: see include/o2345.h (1.5: o2345_list_sort_by_visibility; 1.4: color stats, bf16 entry removed; 1.3: o2345_conv2d family; 1.2: t_rand)
+
+int o2345_preload(void) {
+    int e, bad = 0;
+    if ((e = o2345::preload_costvol())) bad = e;
+    if ((e = o2345::preload_sparse())) bad = e;
+    if ((e = o2345::preload_sparse_mfma())) bad = e;
+    if ((e = o2345::preload_sdf_mlp())) bad = e;
+    if ((e = o2345::preload_sdf_mlp_x3())) bad = e;
+    if ((e = o2345::preload_render())) bad = e;
+    if ((e = o2345::preload_list_sort())) bad = e;
+    if ((e = o2345::preload_color_maps())) bad = e;
+    if ((e = o2345::preload_color_pts())) bad = e;
+    if ((e = o2345::preload_mcubes())) bad = e;
+    if ((e = o2345::preload_mesh_pack())) bad = e;
+    if ((e = o2345::preload_featmaps())) bad = e;
+    if ((e = o2345::preload_convnet())) bad = e;
+    O2345_REQUIRE(bad == 0, "preload: hipFuncGetAttributes failed (%s)", hipGetErrorString((hipError_t)bad));
+    return 0;
+}
 
 const char* o2345_knobs(void) {
     static const struct Text { char s[160]; Text() { const o2345::Knobs& k = o2345::knobs();

@@ -140,3 +140,11 @@ int o2345_camera_terms(const float* intrinsics, const float* w2cs, int V, float*
 }
 
 }  // extern "C"
+
+// o2345_preload (csrc/api.cpp): querying one kernel makes the HIP runtime load this translation unit's code object on the current device
+namespace o2345 {
+int preload_color_maps() {
+    hipFuncAttributes at;
+    return (int)hipFuncGetAttributes(&at, (const void*)(k_pack_cmaps));
+}
+}  // namespace o2345

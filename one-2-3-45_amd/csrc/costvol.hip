@@ -407,3 +407,11 @@ int o2345_scatter_dense(const float* rows, const int32_t* row_of_voxel, int C, l
 }
 
 }  // extern "C"
+
+// o2345_preload (csrc/api.cpp): querying one kernel makes the HIP runtime load this translation unit's code object on the current device
+namespace o2345 {
+int preload_costvol() {
+    hipFuncAttributes at;
+    return (int)hipFuncGetAttributes(&at, (const void*)(k_scan_small));
+}
+}  // namespace o2345

@@ -148,3 +148,11 @@ int o2345_pyramid_pack(const float* f2, const float* s1, const float* s0, const 
 }
 
 }  // extern "C"
+
+// o2345_preload (csrc/api.cpp): querying one kernel makes the HIP runtime load this translation unit's code object on the current device
+namespace o2345 {
+int preload_featmaps() {
+    hipFuncAttributes at;
+    return (int)hipFuncGetAttributes(&at, (const void*)(k_pyramid_pack));
+}
+}  // namespace o2345

@@ -278,3 +278,11 @@ int o2345_marching_cubes_emit(const float* u, int n0, int n1, int n2, double iso
 }
 
 }  // extern "C"
+
+// o2345_preload (csrc/api.cpp): querying one kernel makes the HIP runtime load this translation unit's code object on the current device
+namespace o2345 {
+int preload_mcubes() {
+    hipFuncAttributes at;
+    return (int)hipFuncGetAttributes(&at, (const void*)(k_scan_small3));
+}
+}  // namespace o2345

@@ -792,3 +792,11 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
 }
 
 }  // extern "C"
+
+// o2345_preload (csrc/api.cpp): querying one kernel makes the HIP runtime load this translation unit's code object on the current device
+namespace o2345 {
+int preload_render() {
+    hipFuncAttributes at;
+    return (int)hipFuncGetAttributes(&at, (const void*)(k_quirk_min2));
+}
+}  // namespace o2345

@@ -309,3 +309,11 @@ int o2345_sdf_mlp_ex(int variant, const float* blob, const float* vol_cl, int D,
 }
 
 }  // extern "C"
+
+// o2345_preload (csrc/api.cpp): querying one kernel makes the HIP runtime load this translation unit's code object on the current device
+namespace o2345 {
+int preload_sdf_mlp() {
+    hipFuncAttributes at;
+    return (int)hipFuncGetAttributes(&at, (const void*)(k_sdf_mlp<0>));
+}
+}  // namespace o2345

@@ -531,3 +531,11 @@ int o2345_sdf_grid_x3(const float* blob, const float* vol_cl, int D, int grid_R,
 }
 
 }  // extern "C"
+
+// o2345_preload (csrc/api.cpp): querying one kernel makes the HIP runtime load this translation unit's code object on the current device
+namespace o2345 {
+int preload_sdf_mlp_x3() {
+    hipFuncAttributes at;
+    return (int)hipFuncGetAttributes(&at, (const void*)(k_sdf_grad_x3));
+}
+}  // namespace o2345

@@ -308,3 +308,11 @@ int o2345_sparse_conv3d_x3(int mode, const float* in, int cin, const int32_t* in
 }
 
 }  // extern "C"
+
+// o2345_preload (csrc/api.cpp): querying one kernel makes the HIP runtime load this translation unit's code object on the current device
+namespace o2345 {
+int preload_sparse_mfma() {
+    hipFuncAttributes at;
+    return (int)hipFuncGetAttributes(&at, (const void*)(k_sparse_conv_brick_32_16));
+}
+}  // namespace o2345

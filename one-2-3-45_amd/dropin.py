@@ -56,6 +56,14 @@ class _AliasFinder(importlib.abc.MetaPathFinder):
         return None
 
 
+def cpu_threads():
+    """Intra-op CPU threads for a drop-in run: $O2345_CPU_THREADS, else min(8, cores).  The reference's trainer does a handful of SMALL tensor ops on the
+    host inside its timing brackets (torch.tensor(vertices).to(...), colours * 255, ...); with torch's default of one thread per core the OpenMP
+    fork / join of each costs 50 - 70 ms on a 256-core MI355X host (measured: export_mesh_step 33 ms with 8 threads, 35 - 100 ms with 128)."""
+    n = os.environ.get("O2345_CPU_THREADS")
+    return max(1, int(n)) if n else max(1, min(8, os.cpu_count() or 1))
+
+
 def install():
     if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):
         sys.meta_path.insert(0, _AliasFinder())
@@ -64,6 +72,9 @@ def install():
 def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
+    # before anything imports torch: the thread pools read these at start-up (an explicit OMP_NUM_THREADS of the user wins)
+    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(var, str(cpu_threads()))
     install()
     script = sys.argv[1]
     sys.argv = sys.argv[1:]

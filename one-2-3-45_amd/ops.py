@@ -76,6 +76,20 @@ def to_host_numpy(*tensors):
     return [h.numpy() for h in out]
 
 
+_preloaded = set()
+
+
+def preload(device):
+    """Load every code object of the library on ``device`` now (o2345_preload) -- once per device and process.  The mirrors call it when weights are loaded,
+    so that the HIP runtime's lazy per-translation-unit loading (5 - 60 ms each) does not land inside the first timed call of a fresh process."""
+    device = torch.device(device)
+    if device.type != "cuda" or device in _preloaded:
+        return
+    with torch.cuda.device(device):
+        check(_lib.lib().o2345_preload(), "preload")
+    _preloaded.add(device)
+
+
 _ws_cache = {}
 
 
@@ -675,6 +689,17 @@ def mesh_pack(verts_idx, tris, grid_R, bound_min=(-1.0, -1.0, -1.0), bound_max=(
                                      _p(vrec, torch.uint8), _stream()), "mesh_pack_vertices")
     check(L.o2345_mesh_pack_faces(_p(tris, tris.dtype), 8 if tris.dtype == torch.int64 else 4, m, _p(frec, torch.uint8), _stream()), "mesh_pack_faces")
     return vrec, frec
+
+
+@_on_device
+def mc_verts_to_world(verts_idx, grid_R, bound_min, bound_max):
+    """Index-space marching-cubes vertices (fp64 [N,3] on the device) -> world coordinates IN PLACE: v / (R - 1) * (bound_max - bound_min) + bound_min in
+    fp64 (sparse_neus_renderer.py:936), the same IEEE expression numpy evaluates on the host.  bound_min / bound_max: three numbers each."""
+    bmin = np.ascontiguousarray(np.asarray(bound_min, np.float64).reshape(3))
+    bmax = np.ascontiguousarray(np.asarray(bound_max, np.float64).reshape(3))
+    check(_lib.lib().o2345_mc_verts_to_world(_p(verts_idx, torch.float64), verts_idx.shape[0], int(grid_R), bmin.ctypes.data_as(ctypes.c_void_p),
+                                             bmax.ctypes.data_as(ctypes.c_void_p), _stream()), "mc_verts_to_world")
+    return verts_idx
 
 
 @_on_device

@@ -199,9 +199,11 @@ class SparseNeuSRenderer(nn.Module):
             e = torch.nn.functional.interpolate((1 - occupancy_mask)[None, None].float(), [resolution] * 3, mode="nearest")[0, 0] > 0
             u = torch.where(e.to(u.device), torch.full_like(u, -100.0), u)
         v, t = ops.marching_cubes(u.contiguous(), float(threshold))
-        # the reference returns numpy (vertices float64 in world units, triangles, u): three copies into pinned memory, one synchronisation
-        vh, th, uh = ops.to_host_numpy(v, t, u)
+        # the reference returns numpy (vertices float64 in world units, triangles, u): index -> world on the device (fp64, the expression numpy would
+        # evaluate), then three copies into pinned memory and one synchronisation
         bmin = torch.as_tensor(bound_min).double().cpu().numpy()
         bmax = torch.as_tensor(bound_max).double().cpu().numpy()
-        verts = vh / (resolution - 1.0) * (bmax - bmin)[None, :] + bmin[None, :]
-        return verts, th, uh
+        if v.shape[0]:
+            ops.mc_verts_to_world(v, resolution, bmin, bmax)
+        vh, th, uh = ops.to_host_numpy(v, t, u)
+        return vh, th, uh

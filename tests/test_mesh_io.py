@@ -30,6 +30,15 @@ def test_ply_roundtrip_and_shim(pkg, tmp_path):
     assert c3 is None and np.array_equal(v3, v.astype(np.float32))
     mio.write_ply(p, np.zeros((0, 3)), np.zeros((0, 3), np.int64))
     assert mio.read_ply(p)[0].shape == (0, 3)
+    # the library's host-side record packer (o2345_ply_records_host, threaded above 65,536 records) == the numpy structured-array definition, byte for byte
+    big_v = rng.normal(0, 3, (70001, 3))
+    big_f = rng.integers(0, 70001, (90003, 3))
+    for cols in (None, rng.integers(0, 256, (70001, 3)).astype(np.uint8), rng.integers(0, 256, (70001, 4)).astype(np.uint8)):
+        mio.write_ply(p, big_v, big_f, cols)
+        mio.write_ply_numpy(str(tmp_path / "ref.ply"), big_v, big_f, cols)
+        assert open(p, "rb").read() == open(str(tmp_path / "ref.ply"), "rb").read()
+    with pytest.raises(ValueError):
+        mio.write_ply(p, v, f, c[:50])
     tm = importlib.import_module("one-2-3-45_amd.shims.trimesh")
     tm.Trimesh(v, f, vertex_colors=c).export(p)
     v4, f4, c4 = mio.read_ply(p)

@@ -229,7 +229,23 @@ def _bracket(fn, reps):
 
 
 def run(dev, reps=3, resolution=256, cold=False, val=True, out_dir="/tmp/o2345_dropin"):
-    """-> dict for bench.py's ``dropin`` block.  ``cold``: the caller is a fresh process; the first bracket is reported separately."""
+    """-> dict for bench.py's ``dropin`` block.  ``cold``: the caller is a fresh process; the first bracket is reported separately.
+    The host-side tensor ops of the trainer run with the intra-op thread count the drop-in launcher sets (dropin.cpu_threads(): min(8, cores) unless
+    $O2345_CPU_THREADS says otherwise) -- restored afterwards."""
+    import torch
+    threads = importlib.import_module("one-2-3-45_amd.dropin").cpu_threads()
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        res = _run(dev, reps, resolution, cold, val, out_dir)
+    finally:
+        torch.set_num_threads(old_threads)
+    res["cpu_threads"] = threads
+    res["cpu_cores"] = os.cpu_count()
+    return res
+
+
+def _run(dev, reps, resolution, cold, val, out_dir):
     import torch
     res = {"workload": "reference configuration: V=32 views 256^2, 96^3 volume, 256^3 extraction grid, 64+64 samples; the trainer's own call order on recon/* + shims",
            "reference_published_export_mesh_s": 2.4887, "reference_bracket": "models/trainer_generic.py:1086-1094 (export mesh time), :1072-1083 (val_step time)"}
@@ -279,6 +295,8 @@ def run(dev, reps=3, resolution=256, cold=False, val=True, out_dir="/tmp/o2345_d
 def cold_process(profile=False):
     """Everything a fresh process pays before and inside its first bracket (run.py:61-67 spawns one process per shape)."""
     res = {"python_start_to_main_ms": (time.perf_counter() - T_START) * 1e3}
+    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):           # what `python -m o2345_amd.dropin <script>` does before torch is imported
+        os.environ.setdefault(var, str(importlib.import_module("one-2-3-45_amd.dropin").cpu_threads()))
     t0 = time.perf_counter()
     import torch
     res["import_torch_ms"] = (time.perf_counter() - t0) * 1e3
