@@ -362,6 +362,25 @@ def cpu_baseline_and_parity(wt, vol, inp, D, n_rays, budget_s=15.0):
     return cpu, par
 
 
+CURRENT_ROUND = 4
+
+
+def cpu_reference_file():
+    """The reference's OWN modules timed on CPU (tools/time_reference_cpu.py, build container only: the GPU box has no /root/reference): the newest
+    profiles/rNN_cpu_reference.json, attached only when it was generated in THIS round (the file carries round / commit / date / host / core count);
+    a stale file is refused with the reason instead of being re-attached to every line forever."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_cpu_reference.json")))
+    if not files:
+        return {"refused": "no profiles/rNN_cpu_reference.json (run tools/time_reference_cpu.py in the build container)"}
+    d = json.load(open(files[-1]))
+    meta = d.get("_meta") or {}
+    rel = os.path.relpath(files[-1], ROOT)
+    if meta.get("round") != f"r{CURRENT_ROUND:02d}":
+        return {"refused": f"{rel} was measured in round {meta.get('round', 'unknown (no _meta stamp)')}, this is round r{CURRENT_ROUND:02d}: re-run tools/time_reference_cpu.py"}
+    return dict(d, source=rel)
+
+
 def median_ms(fn, reps=5):
     fn(); torch.cuda.synchronize()
     ts = []
@@ -408,24 +427,41 @@ def config5_block(dev, wt, a):
 
 def c3_block(dev, wt, inp, a, rank, world):
     """BASELINE config 3: 32 distinct scenes dealt over the ranks (scenes_for_rank: scene k on rank k mod world), each scene's images uploaded
-    host -> device INSIDE the step (pinned staging buffer, 6.3 MB), whole scene pass per scene."""
+    host -> device INSIDE the step (pinned staging buffer, 6.3 MB), whole scene pass per scene.  Every rank also reports its own clock, scene rate and
+    the time its uploads took (HIP events around the copies), so that the first real 8-GPU run attributes a loss to PCIe / host / kernels without a second run."""
     n_scenes = 32
     mine = sharding.scenes_for_rank(n_scenes, rank, world)
     host = [torch.from_numpy(scene_images(a.views, 1000 + k)).pin_memory() for k in mine]
     tm = Timer()
     out = step(wt, inp, a.vol, a.mesh_res, tm, a.ray_chunk)           # warm
     out = None
+    tm.collect(); tm.acc = {}
+    ev = []
     sharding.barrier(dev)
     t0 = time.perf_counter()
     for h in host:
         out = None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         imgs = h.to(dev, non_blocking=True)
+        e1.record()
+        ev.append((e0, e1))
         out = step(wt, inp, a.vol, a.mesh_res, tm, a.ray_chunk, imgs=imgs)
+    torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0
     sharding.barrier(dev)
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    tm.collect()
+    h2d_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
     n_rays = inp["rays_o"].shape[0]
+    mine_report = {"rank": rank, "scenes": len(mine), "seconds_own_clock": t_own, "scenes_per_s_own_clock": len(mine) / t_own if t_own > 0 else None,
+                   "h2d_ms_per_scene_mean_max": [float(np.mean(h2d_ms)), float(np.max(h2d_ms))] if h2d_ms else None,
+                   "h2d_gb_per_s": (host[0].numel() * 4 / 1e9) / (np.mean(h2d_ms) * 1e-3) if h2d_ms else None,
+                   "kernel_ms_per_scene": {k: float(np.mean(v)) for k, v in tm.acc.items()}}
+    per_rank = sharding.gather_objects(mine_report)
     return {"workload": f"{n_scenes} distinct scenes, {len(mine)} per GPU on {world} GPU(s), images uploaded inside the step",
-            "scenes": n_scenes, "scenes_per_s": n_scenes / dt, "rays_per_s": n_scenes * n_rays / dt, "seconds": dt, "h2d_bytes_per_scene": int(host[0].numel() * 4)}
+            "scenes": n_scenes, "scenes_per_s": n_scenes / dt, "rays_per_s": n_scenes * n_rays / dt, "seconds": dt, "h2d_bytes_per_scene": int(host[0].numel() * 4),
+            "per_rank": per_rank}
 
 
 def dropin_block(dev):
@@ -616,9 +652,7 @@ def main():
         if world == 1 and not a.no_cpu:
             vol0 = pipeline.build_volume(wt, inp["imgs"], inp["aff"], inp["origin"], a.vol, 2.0 / (a.vol - 1))     # the scene cpu_baseline's images belong to
             result["cpu_baseline"], result["parity_fullsize"] = cpu_baseline_and_parity(wt, vol0, inp, a.vol, a.cpu_rays)
-            ref_file = os.path.join(ROOT, "profiles", "r02_cpu_reference.json")
-            if os.path.exists(ref_file):
-                result["cpu_baseline_reference"] = json.load(open(ref_file))
+            result["cpu_baseline_reference"] = cpu_reference_file()
             vol0 = None
         if world == 1 and not a.quick:
             vol = outs = mesh = None

@@ -30,6 +30,7 @@ def sources_sha():
         if f.endswith((".hip", ".h", ".cpp")):
             h.update(f.encode())
             h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(HERE), "include", "o2345.h"), "rb").read())       # csrc/common.h includes the public header
     return h.hexdigest()[:16]
 
 

@@ -81,7 +81,7 @@ PAIRS = (("color", "color_fine"), ("depth", "depth"), ("weights", "weights"), ("
 
 @torch.no_grad()
 def three_clause(ops, dev, scene, a, ro, rd, near, far, variance=0.2, air=1.0, bg=1.0, precision="f16x3", chunk=None, sampler=True,
-                 label="", n_samples=64, n_importance=64, quantiles=True):
+                 label="", n_samples=64, n_importance=64, quantiles=True, e2e_caps=None):
     """scene: the device dict of ops.render_rays; a: oracle arguments (volume [C,D,D,D], maskvol [D,D,D], W, RW, feat_maps, color_maps, w2cs,
     K, img_wh, query_c2w); ro / rd: CPU float32 [R,3]; bg: None (the reference's background_rgb=None: nothing added) or a float.
     chunk: rays per call on BOTH sides (the reference's per-call quirks -- cat_z_vals' "<= 1 valid point" rule -- then apply identically).
@@ -146,6 +146,20 @@ def three_clause(ops, dev, scene, a, ro, rd, near, far, variance=0.2, air=1.0, b
     print(f"[{label} {precision} inv_s={inv_s:.1f} air={air} bg={bg}] {len(dev_rays)} of {R} rays deviate end to end; ray ids {dev_rays.tolist()[:40]}; "
           f"their sample lists differ by {[round(float(x), 7) for x in zerr[dev_rays][:8]]}", file=sys.stderr)
     assert bool((zerr[dev_rays] > 1e-6).all()), (label, "a deviating ray has coinciding sample lists")
+    # Hard regression caps on the END-TO-END error, independent of the sensitivity argument above (a sampler regression that changes many sample lists
+    # must not hide inside "4 x the oracle's own sensitivity").  Measured at BASELINE config 2 on the driver's 4,320 rays (BENCH_r03 parity_fullsize):
+    # colour max 4.2e-2, q99 3.1e-3, 2.2 % of the rays above 1e-3, 9.1 % above 1e-4.
+    res["e2e"]["frac_color_gt_1e-3"] = float((cerr > 1e-3).float().mean())
+    res["e2e"]["frac_rays_with_other_lists_and_color_gt_bound"] = float(len(dev_rays)) / R
+    if e2e_caps is None:
+        e2e_caps = variance <= 0.3                  # the caps are calibrated in the regime the benchmark runs in (inv_s = 7.4 ... 20); a trained model's inv_s = 90 ... 665
+    if e2e_caps:                                    # sharpens every list difference into an O(1) colour difference -- there the sensitivity-scaled clauses are the contract
+        assert float(cerr.max()) <= 6e-2, (label, "end-to-end colour error above the 6e-2 cap", res["e2e"])
+        if R >= 64:
+            assert res["e2e"]["frac_color_gt_1e-3"] <= 0.06, (label, "more than 6 % of the rays deviate by more than 1e-3", res["e2e"])
+            assert len(dev_rays) <= 0.25 * R, (label, "more than a quarter of the rays have other sample lists AND deviate", res["e2e"])
+        if R >= 1000:
+            assert float(torch.quantile(cerr, 0.99)) <= 8e-3, (label, "q99 of the end-to-end colour error above 8e-3", res["e2e"])
     if quantiles and R >= 64:
         sens = _noisy(lambda: _render(a, ro, rd, near, far, var_t, air, bgv, chunk)[0])
         ce = torch.stack([(n["color_fine"] - ref["color_fine"]).abs().max(1).values for n in sens])

@@ -1,8 +1,9 @@
 """Times the REFERENCE's own modules (imported from /root/reference, CPU, stubs per oracle/ref_import.py) on BASELINE config-2 inputs:
 SparseNeuSRenderer.render (512-ray chunks, like the runner) and extract_fields.  Build container only (the GPU box has no
-/root/reference); writes profiles/r02_cpu_reference.json, which bench.py attaches as `cpu_baseline_reference`.
+/root/reference); writes profiles/rNN_cpu_reference.json (NN = the current round, tools/profile_round.sh's tag) stamped with the commit, date, host and
+core count it was measured on; bench.py attaches the NEWEST such file as `cpu_baseline_reference` and refuses one from an older round.
 
-    python tools/time_reference_cpu.py [seconds]"""
+    python tools/time_reference_cpu.py [seconds] [round tag, default r04]"""
 import importlib
 import json
 import os
@@ -23,6 +24,7 @@ pkg = importlib.import_module("one-2-3-45_amd")
 @torch.no_grad()
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+    tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
     V, HW, D = 8, 256, 128
     sc = pkg.synth.make_scene(V, image_seed=0)
     sdfnet, rnet, var, renderer = RI.build_networks(D, seed=0)
@@ -58,7 +60,15 @@ def main():
            "value": done / dt, "unit": "rays/s", "cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "kind": "reference",
            "sample": f"{done} rays in 512-ray chunks (the runner's batch size), {dt:.1f} s",
            "extract_fields_points_per_s": R ** 3 / de, "extract_fields_sample": f"{R}^3 grid, {de:.1f} s (a 256^3 grid is 64x that)"}
-    path = os.path.join(ROOT, "profiles", "r02_cpu_reference.json")
+    import datetime
+    import platform
+    import subprocess
+    git = lambda *a: subprocess.run(["git", "-C", ROOT] + list(a), capture_output=True, text=True).stdout.strip()
+    out["_meta"] = {"round": tag, "commit": git("rev-parse", "--short", "HEAD"), "dirty": bool(git("status", "--porcelain", "--", "oracle", "one-2-3-45_amd")),
+                    "date_utc": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ"), "host": platform.node(), "nproc": os.cpu_count(),
+                    "cpu": next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?"), "torch": torch.__version__,
+                    "script": "tools/time_reference_cpu.py"}
+    path = os.path.join(ROOT, "profiles", f"{tag}_cpu_reference.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out))
 
