@@ -150,10 +150,10 @@ __global__ __launch_bounds__(256) void k_ray_stream(RoundArgs a, float* __restri
     if (MERGE) {
         float nz[NFIX], ns[NFIX];
         unsigned nt[NFIX];
+        const bool z_only = MODE == RM_FINALIZE && !a.merge_all_lists;
 #pragma unroll
         for (int j = 0; j < NFIX; ++j) {
             nz[j] = a.new_z[(size_t)j * R + rr];
-            const bool z_only = MODE == RM_FINALIZE && !a.merge_all_lists;
             ns[j] = z_only ? 0.f : a.new_sdf[(size_t)j * R + rr];
             nt[j] = (a.new_msk && !z_only) ? a.new_msk[(size_t)j * R + rr] : 0u;
         }
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_ray_stream(RoundArgs a, float* __restri
 #pragma unroll
         for (int j = 0; j + 1 < NFIX; ++j) sorted = sorted && !(nz[j] > nz[j + 1]);
         if (live) {                                 // in-place on the global lists: lanes past the last ray must not write
-            if (MODE == RM_FINALIZE && !a.merge_all_lists) {
+            if (z_only) {
                 GlobalMergeZ m{a.z, (size_t)R, r};
                 merge_core_fixed<GlobalMergeZ, NFIX>(m, S, nz, ns, nt, sorted);
             } else {
@@ -523,7 +523,8 @@ __global__ __launch_bounds__(64) void k_ray_merge_any(int R, float* z, float* sd
             nt[j] = new_msk ? new_msk[(size_t)(base + j) * R + r] : 0u;
         }
         GlobalMergeTag a{z, sdf, msk, (size_t)R, r};
-        merge_core<GlobalMergeTag, NMAX>(a, S + base, nz, ns, nt, nb);
+        ArrayBlock blk{nz, ns, nt};
+        merge_core(a, S + base, blk, nb);
     }
 }
 

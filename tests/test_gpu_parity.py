@@ -751,3 +751,30 @@ def test_chunked_render_equals_one_call(dev, ops):
         for k in per_sample:
             assert torch.equal(part[k], whole[k][:, c0:c0 + 512]), (k, c0)
     assert float(whole["weights_sum"].max()) > 0.5
+
+
+def test_camera_terms_and_world_vertices(dev, ops):
+    """o2345_camera_terms == intrinsics @ w2cs[:, :3, :] and inverse(w2cs)[:, :3, 3] (what the reference computes with torch.matmul / torch.inverse,
+    models/render_utils.py:106, models/projector.py:60-70) -- products as fp32 FMA chains in k order, the inverse by fp64 cofactors -- on rigid poses, on a
+    general (sheared, scaled) affine matrix and for V = 1 / 32 / 70; o2345_mc_verts_to_world == numpy's fp64 expression, bit for bit; o2345_preload loads."""
+    rng = np.random.default_rng(4)
+    for V in (1, 32, 70):
+        sc = pkg.synth.make_scene(32 if V > 8 else 8)
+        K = np.tile(sc["intrinsics"][:1], (V, 1, 1)).astype(np.float32) * rng.uniform(0.5, 2.0, (V, 1, 1)).astype(np.float32)
+        w2c = np.stack([sc["w2cs"][i % sc["w2cs"].shape[0]] for i in range(V)]).astype(np.float32)
+        if V == 70:                                           # general invertible matrices, not just rigid poses
+            w2c = w2c + rng.normal(0, 0.05, w2c.shape).astype(np.float32)
+        proj, cam = ops.camera_terms(torch.from_numpy(K).to(dev), torch.from_numpy(w2c).to(dev))
+        want_p = K.astype(np.float64) @ w2c[:, :3, :].astype(np.float64)
+        want_c = np.linalg.inv(w2c.astype(np.float64))[:, :3, 3]
+        assert np.abs(proj.cpu().numpy() - want_p).max() <= 3e-7 * np.abs(want_p).max()
+        assert np.abs(cam.cpu().numpy() - want_c).max() <= 2e-7 * max(1.0, np.abs(want_c).max())
+        tp = torch.matmul(torch.from_numpy(K), torch.from_numpy(w2c)[:, :3, :])            # ATen on the CPU evaluates the same FMA chain
+        assert float((proj.cpu() - tp).abs().max()) <= 1e-6 * float(tp.abs().max())
+    v = torch.from_numpy(rng.uniform(0, 255, (100003, 3))).to(dev)
+    ref = v.cpu().numpy() / 255.0 * (np.array([1.0, 1.5, 2.0]) - np.array([-1.0, -0.5, 0.25]))[None, :] + np.array([-1.0, -0.5, 0.25])[None, :]
+    got = ops.mc_verts_to_world(v.clone(), 256, [-1.0, -0.5, 0.25], [1.0, 1.5, 2.0])
+    assert np.array_equal(got.cpu().numpy(), ref)
+    ops._preloaded.discard(dev)
+    ops.preload(dev)
+    assert dev in ops._preloaded
