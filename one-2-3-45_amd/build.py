@@ -75,7 +75,7 @@ def build(force=False, verbose=False):
 
 
 def build_variant(tag, defines, packed_fp32=False):
-    """A second library for A/B runs on ONE box (tools/ab_lib.py): every source recompiled with extra -D flags into build_<tag>/,
+    """A second library for A/B runs on ONE box: every source recompiled with extra -D flags into build_<tag>/,
     linked as libo2345_hip_<tag>.so next to the product library (git-ignored; travels with the gpurun snapshot).  ``packed_fp32=True`` drops
     NO_PACKED_FP32 (the reproducer of the co-resident-MFMA corruption, tools/stress_gather.py)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
