@@ -334,8 +334,9 @@ int o2345_mesh_pack_vertices(const double* verts_idx, long long n, int grid_R, c
                              const float* scale_mat, const float* trans_mat, const float* rgb, uint8_t* vertex_records, void* stream);
 int o2345_mesh_pack_faces(const void* tris, int index_bytes, long long m, uint8_t* face_records, void* stream);
 /* extract_geometry's index -> world step on the device, in place and in fp64 (sparse_neus_renderer.py:936: vertices / (R - 1) * (bound_max - bound_min)
- * + bound_min; the same IEEE expression numpy evaluates): verts [n,3] device fp64, bounds HOST fp64 [3]. */
-int o2345_mc_verts_to_world(double* verts, long long n, int grid_R, const double* bound_min_host, const double* bound_max_host, void* stream);
+ * + bound_min; the same IEEE expression numpy evaluates): verts [n,3] device fp64; extent = bound_max - bound_min (the reference subtracts the fp32 bounds,
+ * THEN promotes) and offset = bound_min as HOST fp64 [3]. */
+int o2345_mc_verts_to_world(double* verts, long long n, int grid_R, const double* extent_host, const double* offset_host, void* stream);
 /* The PLY records of a mesh that is already on the HOST (trimesh.Trimesh(vertices, faces, vertex_colors).export(), trainer_generic.py:1302-1303,
  * 1377-1382): vertices fp64 [n,3], colors uint8 [n,3|4] or NULL, faces int64 [m,3], all host pointers -> vertex_records n x (16 | 12) bytes,
  * face_records m x 13 bytes.  Plain host code (up to four threads), no device work, no stream. */

@@ -93,13 +93,12 @@ int o2345_mesh_pack_vertices(const double* verts_idx, long long n, int grid_R, c
     return check_launch("mesh_pack_vertices");
 }
 
-int o2345_mc_verts_to_world(double* verts, long long n, int grid_R, const double* bound_min_host, const double* bound_max_host, void* stream) {
-    O2345_REQUIRE(bound_min_host && bound_max_host && grid_R >= 2, "mc_verts_to_world: bad bounds / resolution");
+int o2345_mc_verts_to_world(double* verts, long long n, int grid_R, const double* extent_host, const double* offset_host, void* stream) {
+    O2345_REQUIRE(extent_host && offset_host && grid_R >= 2, "mc_verts_to_world: bad extent / offset / resolution");
     if (n <= 0) return 0;
     O2345_REQUIRE(verts, "mc_verts_to_world: null pointer");
-    const double* a = bound_min_host; const double* b = bound_max_host;
-    hipLaunchKernelGGL(k_verts_to_world, dim3(cdiv(3 * n, 256)), dim3(256), 0, (hipStream_t)stream, verts, 3 * n, (double)grid_R - 1.0, b[0] - a[0], b[1] - a[1],
-                       b[2] - a[2], a[0], a[1], a[2]);
+    const double* e = extent_host; const double* o = offset_host;
+    hipLaunchKernelGGL(k_verts_to_world, dim3(cdiv(3 * n, 256)), dim3(256), 0, (hipStream_t)stream, verts, 3 * n, (double)grid_R - 1.0, e[0], e[1], e[2], o[0], o[1], o[2]);
     return check_launch("mc_verts_to_world");
 }
 

@@ -694,11 +694,13 @@ def mesh_pack(verts_idx, tris, grid_R, bound_min=(-1.0, -1.0, -1.0), bound_max=(
 @_on_device
 def mc_verts_to_world(verts_idx, grid_R, bound_min, bound_max):
     """Index-space marching-cubes vertices (fp64 [N,3] on the device) -> world coordinates IN PLACE: v / (R - 1) * (bound_max - bound_min) + bound_min in
-    fp64 (sparse_neus_renderer.py:936), the same IEEE expression numpy evaluates on the host.  bound_min / bound_max: three numbers each."""
-    bmin = np.ascontiguousarray(np.asarray(bound_min, np.float64).reshape(3))
-    bmax = np.ascontiguousarray(np.asarray(bound_max, np.float64).reshape(3))
-    check(_lib.lib().o2345_mc_verts_to_world(_p(verts_idx, torch.float64), verts_idx.shape[0], int(grid_R), bmin.ctypes.data_as(ctypes.c_void_p),
-                                             bmax.ctypes.data_as(ctypes.c_void_p), _stream()), "mc_verts_to_world")
+    fp64 (sparse_neus_renderer.py:936), the same IEEE expression numpy evaluates on the host.  bound_min / bound_max: three float32 numbers each."""
+    b0 = np.asarray(bound_min.detach().cpu() if torch.is_tensor(bound_min) else bound_min, np.float32).reshape(3)
+    b1 = np.asarray(bound_max.detach().cpu() if torch.is_tensor(bound_max) else bound_max, np.float32).reshape(3)
+    ext = np.ascontiguousarray((b1 - b0).astype(np.float64))          # the reference subtracts its float32 bound arrays, numpy promotes afterwards
+    off = np.ascontiguousarray(b0.astype(np.float64))
+    check(_lib.lib().o2345_mc_verts_to_world(_p(verts_idx, torch.float64), verts_idx.shape[0], int(grid_R), ext.ctypes.data_as(ctypes.c_void_p),
+                                             off.ctypes.data_as(ctypes.c_void_p), _stream()), "mc_verts_to_world")
     return verts_idx
 
 

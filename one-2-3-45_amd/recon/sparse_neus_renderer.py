@@ -182,14 +182,24 @@ class SparseNeuSRenderer(nn.Module):
 
     @torch.no_grad()
     def extract_fields(self, bound_min, bound_max, resolution, query_func, device, **kwargs):
-        """u = -sdf on linspace(bound_min, bound_max, resolution)^3 (:881-905).  One fused launch instead of 64 chunks + host syncs;
-        the lattice is generated in-kernel, which requires the reference's own bounds (-1, 1)."""
-        if not (float(torch.as_tensor(bound_min).min()) == -1.0 and float(torch.as_tensor(bound_max).max()) == 1.0):
-            raise NotImplementedError("o2345 extract_fields: bounds (-1, 1) only")
+        """u = -sdf on linspace(bound_min, bound_max, resolution)^3 (:881-905), as a DEVICE tensor [R,R,R].  The reference's own bounds (-1, 1): one fused
+        launch, lattice generated in-kernel, layer 0 from per-axis tables.  Any other box: the three axes from torch.linspace on the host exactly as the
+        reference builds them (:887-889), the lattice points materialised once on the device, one launch of the point kernel (instead of 64 chunks with a
+        device -> host copy each)."""
         vol = kwargs["conditional_volume"]
         layer = self.sdf_network.sdf_layer
-        u = ops.sdf_mlp(layer.blob(), channel_last(vol), None, variant=0, grid_R=resolution, sign=-1.0, grid_tables=layer.grid_tables(resolution))["sdf"]
-        return u.view(resolution, resolution, resolution)
+        R = int(resolution)
+        b0 = torch.as_tensor(bound_min, dtype=torch.float32).reshape(-1).cpu()
+        b1 = torch.as_tensor(bound_max, dtype=torch.float32).reshape(-1).cpu()
+        if bool((b0 == -1.0).all()) and bool((b1 == 1.0).all()):
+            u = ops.sdf_mlp(layer.blob(), channel_last(vol), None, variant=0, grid_R=R, sign=-1.0, grid_tables=layer.grid_tables(R))["sdf"]
+            return u.view(R, R, R)
+        if R ** 3 >= 2 ** 31:
+            raise ValueError("o2345 extract_fields: resolution^3 must stay below 2^31")
+        ax = [torch.linspace(float(b0[d]), float(b1[d]), R).to(vol.device) for d in range(3)]
+        pts = torch.stack(torch.meshgrid(*ax, indexing="ij"), -1).reshape(-1, 3).contiguous()
+        u = ops.sdf_mlp(layer.blob(), channel_last(vol), pts, variant=0, sign=-1.0)["sdf"]
+        return u.view(R, R, R)
 
     @torch.no_grad()
     def extract_geometry(self, sdf_network, bound_min, bound_max, resolution, threshold, device, occupancy_mask=None, **kwargs):
@@ -201,9 +211,7 @@ class SparseNeuSRenderer(nn.Module):
         v, t = ops.marching_cubes(u.contiguous(), float(threshold))
         # the reference returns numpy (vertices float64 in world units, triangles, u): index -> world on the device (fp64, the expression numpy would
         # evaluate), then three copies into pinned memory and one synchronisation
-        bmin = torch.as_tensor(bound_min).double().cpu().numpy()
-        bmax = torch.as_tensor(bound_max).double().cpu().numpy()
         if v.shape[0]:
-            ops.mc_verts_to_world(v, resolution, bmin, bmax)
+            ops.mc_verts_to_world(v, resolution, torch.as_tensor(bound_min, dtype=torch.float32), torch.as_tensor(bound_max, dtype=torch.float32))
         vh, th, uh = ops.to_host_numpy(v, t, u)
         return vh, th, uh

@@ -293,7 +293,7 @@ def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64,
 
 
 def mc_verts_to_world(verts_idx, grid_R, bound_min, bound_max):
-    bmin, bmax = np.asarray(bound_min, np.float64).reshape(3), np.asarray(bound_max, np.float64).reshape(3)
+    bmin, bmax = np.asarray(bound_min, np.float32).reshape(3), np.asarray(bound_max, np.float32).reshape(3)
     verts_idx.copy_(torch.from_numpy(verts_idx.numpy() / (grid_R - 1.0) * (bmax - bmin)[None, :] + bmin[None, :]))
     return verts_idx
 

@@ -772,8 +772,9 @@ def test_camera_terms_and_world_vertices(dev, ops):
         tp = torch.matmul(torch.from_numpy(K), torch.from_numpy(w2c)[:, :3, :])            # ATen on the CPU evaluates the same FMA chain
         assert float((proj.cpu() - tp).abs().max()) <= 1e-6 * float(tp.abs().max())
     v = torch.from_numpy(rng.uniform(0, 255, (100003, 3))).to(dev)
-    ref = v.cpu().numpy() / 255.0 * (np.array([1.0, 1.5, 2.0]) - np.array([-1.0, -0.5, 0.25]))[None, :] + np.array([-1.0, -0.5, 0.25])[None, :]
-    got = ops.mc_verts_to_world(v.clone(), 256, [-1.0, -0.5, 0.25], [1.0, 1.5, 2.0])
+    b0, b1 = np.array([-1.0, -0.53, 0.251], np.float32), np.array([1.0, 1.47, 2.003], np.float32)       # float32 bounds, like the reference's tensors
+    ref = v.cpu().numpy() / 255.0 * (b1 - b0)[None, :] + b0[None, :]
+    got = ops.mc_verts_to_world(v.clone(), 256, torch.from_numpy(b0), torch.from_numpy(b1))
     assert np.array_equal(got.cpu().numpy(), ref)
     ops._preloaded.discard(dev)
     ops.preload(dev)
