@@ -480,7 +480,8 @@ def dropin_block(dev):
         out[name] = {k: d[k] for k in keep if k in d}
     w = out["warm"]
     out["summary"] = {"export_mesh_warm_ms": w["export_mesh_warm_ms_median"], "export_mesh_fresh_process_ms": out["fresh_process_2"].get("export_mesh_first_call_ms"),
-                      "val_step_warm_ms": w.get("val_step_warm_ms_median"), "reference_published_export_mesh_ms": 2488.7,
+                      "val_step_warm_ms": w.get("val_step_warm_ms_median"), "val_step_with_validate_mesh_360_warm_ms": w.get("val_step_with_validate_mesh_360_ms"),
+                      "reference_published_export_mesh_ms": 2488.7,
                       "speedup_vs_published_fresh_process": (2488.7 / out["fresh_process_2"]["export_mesh_first_call_ms"]) if out["fresh_process_2"].get("export_mesh_first_call_ms") else None}
     return out
 

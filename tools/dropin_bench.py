@@ -289,6 +289,13 @@ def _run(dev, reps, resolution, cold, val, out_dir):
         tr.val_step(sample, st=st)
         res["val_step_warm_stages_ms"] = st.ms()
         res["val_rays_per_s_chunked"] = 65536 / (res["val_step_warm_ms_median"] * 1e-3)
+        # what the runner's "val_step time" additionally contains: validate_mesh at its default resolution of 360 (trainer_generic.py:1271, :598-606)
+        tr.val_step(sample, mesh_resolution=360)
+        st = Stages(True)
+        t0 = time.perf_counter()
+        tr.val_step(sample, st=st, mesh_resolution=360)
+        res["val_step_with_validate_mesh_360_ms"] = (time.perf_counter() - t0) * 1e3
+        res["val_step_with_validate_mesh_360_stages_ms"] = st.ms()
     return res
 
 
