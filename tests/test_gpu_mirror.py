@@ -304,3 +304,49 @@ def test_torchsparse_shim_forward_chain_vs_oracle():
     assert rel(ye.F, torch.relu(ref_bn(pre)).detach().numpy()) < 1e-4
     with pytest.raises(RuntimeError):
         net.train()(ts.SparseTensor(feat.cpu(), coords.cpu()))            # HIP-only: no CPU fallback
+
+
+def test_mirror_caches_follow_in_place_updates(S):
+    """The mirrors memoise per-image quantities ON the tensor objects the trainer passes to every chunk (colour map, camera terms, near / far read-backs, the
+    variance scalar, packed weights).  Every cache is keyed by the tensor's version counter: an in-place update of near, of the camera poses, of the
+    variance parameter or of a network weight must change the next render exactly as a fresh tensor with the new values does."""
+    g, G, T = S["G"]["g"], S["G"], S["T"]
+    sc, HW = G["sc"], G["cfg"]["HW"]
+    dense, mask = T(g["dense"])[None], T(g["mask"])[None, None]
+    ro, rd = T(G["ro"]), T(G["rd"])
+    near, far = T(sc["query_near_far"][:1]).clone(), T(sc["query_near_far"][1:]).clone()
+    w2cs, K = T(sc["w2cs"]).clone(), T(sc["intrinsics"]).clone()
+    fm, cm, qc = T(G["fmaps"]), T(sc["images"]), T(sc["query_c2w"])[None]
+
+    def render(near_, far_, w2cs_, K_):
+        return S["ren"].render(ro, rd, near_, far_, S["sdf"], S["rnet"], perturb_overwrite=0, background_rgb=1.0, alpha_inter_ratio=1.0, lod=0,
+                               conditional_volume=dense, conditional_valid_mask_volume=mask, feature_maps=fm, color_maps=cm, w2cs=w2cs_, intrinsics=K_,
+                               img_wh=[HW, HW], query_c2w=qc, if_render_with_grad=False)
+    a = render(near, far, w2cs, K)
+    assert torch.equal(render(near, far, w2cs, K)["color_fine"], a["color_fine"])              # served from the caches: same result
+    near.add_(0.05)                                                                            # in place: same object, new version
+    b = render(near, far, w2cs, K)
+    assert torch.equal(b["color_fine"], render(near.clone(), far.clone(), w2cs.clone(), K.clone())["color_fine"])
+    assert not torch.equal(b["depth"], a["depth"])
+    K[:, 0, 0].mul_(1.1)                                                                       # other intrinsics behind the same w2cs object
+    c = render(near, far, w2cs, K)
+    assert torch.equal(c["color_fine"], render(near.clone(), far.clone(), w2cs.clone(), K.clone())["color_fine"]) and not torch.equal(c["color_fine"], b["color_fine"])
+    var = S["var"].variance
+    old = var.detach().clone()
+    try:
+        with torch.no_grad():
+            var.add_(0.2)                                                                      # a trained variance: inv_s must follow
+        d = render(near, far, w2cs, K)
+        assert float(d["variance"]) != float(c["variance"]) and not torch.equal(d["weights"], c["weights"])
+        lin = S["sdf"].sdf_layer.lin2
+        w_old = lin.bias.detach().clone()
+        with torch.no_grad():
+            lin.bias[0] += 0.05                                                                # shifts the SDF: the packed blob must be rebuilt
+        e = render(near, far, w2cs, K)
+        assert not torch.equal(e["sdf"], d["sdf"])
+        with torch.no_grad():
+            lin.bias.copy_(w_old)
+        assert torch.equal(render(near, far, w2cs, K)["sdf"], d["sdf"])
+    finally:
+        with torch.no_grad():
+            var.copy_(old)
