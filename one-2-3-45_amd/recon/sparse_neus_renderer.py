@@ -6,23 +6,7 @@ import torch.nn as nn
 
 from .. import ops
 from .rendering_network import DeferredColour
-from .sparse_sdf_network import channel_last
-
-
-def _attr_cache(t, name, key, make):
-    """A value derived from tensor ``t`` (and nothing that ``key`` does not capture), memoised ON the tensor object: valid while the same object has
-    the same version counter (any in-place write bumps it).  The trainer hands the SAME tensors to every 512-ray chunk of an image
-    (trainer_generic.py:365-416 slices the sample dict once, then loops), so per-image work is done once, not 128 times."""
-    hit = getattr(t, name, None)
-    k = (t._version,) + tuple(key)
-    if hit is not None and hit[0] == k:
-        return hit[1]
-    val = make()
-    try:
-        setattr(t, name, (k, val))
-    except Exception:                      # a tensor subclass without a __dict__: just do not cache
-        pass
-    return val
+from .sparse_sdf_network import _attr_cache, channel_last
 
 
 def _scene_maps(feature_maps, color_maps, w2cs, intrinsics):
@@ -125,7 +109,7 @@ class SparseNeuSRenderer(nn.Module):
             keep = torch.sort(torch.randperm(idx.numel(), generator=g)[:maximum_pts]).values.to(idx.device)
             idx = idx[keep]
         coords = coords_volume.reshape(3, -1).t()[idx]
-        feat = feature_volume.reshape(C, -1).t()[idx] if getattr(feature_volume, "_o2345_cl", None) is None else feature_volume._o2345_cl.reshape(-1, C)[idx]
+        feat = feature_volume.reshape(C, -1).t()[idx]
         return torch.cat([torch.zeros(idx.numel(), 1, device=coords.device, dtype=coords.dtype), coords], dim=1), feat.contiguous()
 
     @torch.no_grad()

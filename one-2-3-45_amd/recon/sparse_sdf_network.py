@@ -24,16 +24,26 @@ def _spnn():
     return _tsnn
 
 
+def _attr_cache(t, name, key, make):
+    """A value derived from tensor ``t`` (and nothing that ``key`` does not capture), memoised ON the tensor object: valid while the same object has
+    the same version counter (any in-place write bumps it).  The trainer hands the SAME tensors to every 512-ray chunk of an image
+    (trainer_generic.py:365-416 slices the sample dict once, then loops), so per-image work is done once, not 128 times."""
+    hit = getattr(t, name, None)
+    k = (t._version,) + tuple(key)
+    if hit is not None and hit[0] == k:
+        return hit[1]
+    val = make()
+    try:
+        setattr(t, name, (k, val))
+    except Exception:                      # a tensor subclass without a __dict__: just do not cache
+        pass
+    return val
+
+
 def channel_last(volume):
-    """[1,C,D,D,D] reference layout -> [D,D,D,C] sampler layout (cached on the tensor object when we produced it)."""
-    cl = getattr(volume, "_o2345_cl", None)
-    if cl is None:
-        cl = volume[0].permute(1, 2, 3, 0).contiguous()
-        try:
-            volume._o2345_cl = cl
-        except Exception:
-            pass
-    return cl
+    """[1,C,D,D,D] reference layout -> [D,D,D,C] sampler layout, memoised on the tensor object per version (get_conditional_volume attaches the
+    channel-last copy its scatter kernel wrote anyway, so the volumes the trainer passes around are never re-laid out)."""
+    return _attr_cache(volume, "_o2345_cl", (), lambda: volume[0].permute(1, 2, 3, 0).contiguous())
 
 
 class LatentSDFLayer(nn.Module):
@@ -203,7 +213,7 @@ class SparseSdfNetwork(nn.Module):
             row = ops.build_index_grid(coords, 1, D)
             rows16 = self._costreg(rows.device).forward(feat, coords, row, D)
         cl, cf, mask = ops.scatter_dense(rows16, row, D, want_cf=True)
-        cf._o2345_cl = cl
+        cf._o2345_cl = ((cf._version,), cl)          # channel_last()'s memo: the same data in the samplers' layout, written by the same kernel
         lod_ = self.lod
         lk = (D, str(cf.device))
         if lk not in self._lattice:              # the voxel-index lattice only depends on the volume size: built once (five launches), returned read-only by contract
