@@ -779,3 +779,28 @@ def test_camera_terms_and_world_vertices(dev, ops):
     ops._preloaded.discard(dev)
     ops.preload(dev)
     assert dev in ops._preloaded
+
+
+@pytest.mark.parametrize("ns,ni", [(32, 32), (48, 80)])
+def test_render_with_other_sample_counts(dev, ops, ns, ni, lib_instance):
+    """n_importance / 4 != 16 new samples per round (the renderer is built around 16: fused merge with the block in registers): the merge then runs as its
+    own launch on the global lists (k_ray_merge_any, the pointer-walk form of render_math.h).  Three-clause contract against the oracle with the same
+    sample counts, and the two kernel forms still bit-identical."""
+    import render_check as RC
+    s = small_scene()
+    d = dev_scene(s, dev, ops)
+    sc = s["sc"]
+    a = _oracle_args(s, 0.0)
+    scene = {k: d[k] for k in ("sdf_blob", "color_mfma_blob", "color_x3_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos")}
+    ro, rd = rays_for(s, 80, seed=ns + ni)
+    near, far = float(sc["query_near_far"][0]), float(sc["query_near_far"][1])
+    res = RC.three_clause(ops, dev, scene, a, torch.from_numpy(ro), torch.from_numpy(rd), near, far, 0.2, 1.0, 1.0, "f16x3", label=f"{ns}+{ni} samples",
+                          n_samples=ns, n_importance=ni, strict_e2e=False)
+    assert res["rays_hitting_surface"] > 10 and res["e2e"]["color_max"] < 6e-2, res
+    qcam = torch.from_numpy(sc["query_c2w"][:3, 3].copy()).to(dev)
+    outs = {}
+    for name, thr in (("group", "1000000000"), ("stream", "0")):
+        lib_instance({"O2345_RAY_STREAM_MIN": thr})
+        outs[name] = ops.render_rays(scene, torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev), near, far, ns, ni, 7.4, 1.0, 1.0, qcam, want_z=True)
+    for k, v in outs["group"].items():
+        assert torch.equal(v, outs["stream"][k]), k
