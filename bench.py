@@ -636,8 +636,10 @@ def main():
             "roofline": dict(rl["color"], traffic=pmc_traffic(COLOR_KERNEL_PREFIX),
                              traffic_source=(f"{PMC_FILE} (bytes, 2*FETCH_SIZE+WRITE_SIZE; collected on these kernel sources)" if PMC_DATA is not None else PMC_STALE),
                              issue_model=pmc_issue_model(COLOR_KERNEL_PREFIX, kt["color_ms"]), rocprof=pmc_mfma_busy(COLOR_KERNEL_PREFIX + "<true")),
-            "roofline_sdf": dict(rl["sdf"], rocprof=pmc_mfma_busy("k_sdf_mlp_x3<false>" if wt.sdf_precision == "f16x3" else "k_sdf_mlp<0>")),
-            "roofline_sdf_grad": dict(rl["sdf_grad"], rocprof=pmc_mfma_busy("k_sdf_grad_x3" if wt.sdf_precision == "f16x3" else "k_sdf_mlp<2>")),
+            "roofline_sdf": dict(rl["sdf"], rocprof=pmc_mfma_busy("k_sdf_mlp_x3<false>" if wt.sdf_precision == "f16x3" else "k_sdf_mlp<0>"),
+                                 traffic=pmc_traffic("k_sdf_mlp_x3<false>" if wt.sdf_precision == "f16x3" else "k_sdf_mlp<0>")),
+            "roofline_sdf_grad": dict(rl["sdf_grad"], rocprof=pmc_mfma_busy("k_sdf_grad_x3" if wt.sdf_precision == "f16x3" else "k_sdf_mlp<2>"),
+                                      traffic=pmc_traffic("k_sdf_grad_x3" if wt.sdf_precision == "f16x3" else "k_sdf_mlp<2>")),
             "roofline_costvol": {"kernel": "k_costvol_gather<16>", "bound": "hbm", "achieved": cv_bytes / (kt["costvol_gather_ms"] * 1e-3) / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cv_bytes / (kt["costvol_gather_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": pmc_traffic("k_costvol_gather"), "algorithmic_bytes": cv_bytes, "ms": kt["costvol_gather_ms"]},
