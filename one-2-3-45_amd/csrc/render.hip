@@ -19,7 +19,9 @@ namespace o2345 {
 __global__ __launch_bounds__(256) void k_ray_coarse(RayGeom g, float near, float far, const float* __restrict__ near_ray,
                                                     const float* __restrict__ far_ray, int S, const float* __restrict__ t_rand,
                                                     float* __restrict__ z, float* __restrict__ pts, const float* __restrict__ maskvol, int D,
-                                                    uint8_t* __restrict__ msk) {
+                                                    uint8_t* __restrict__ msk, int* __restrict__ zero16) {
+    // o2345_render_rays: the first kernel of the call also clears the call's 16 device-side counters (they are first touched by a later launch)
+    if (zero16 && blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0;
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= (long long)S * g.R) return;
     const int s = (int)(p / g.R), r = (int)(p % g.R);
@@ -63,15 +65,8 @@ __device__ __forceinline__ void append_wave(const ValidBits& bits, int n_samples
 }
 
 // cat_z_vals quirk (:137): the SDF of the new points is evaluated only if MORE THAN ONE of them is inside the mask
+// (o2345_render_rays applies it inside the round kernel: round_epilogue; this launch follows the stage entry o2345_ray_upsample)
 __global__ void k_quirk_min2(int* count) { if (*count <= 1) *count = 0; }
-// render_core quirk (:222-223): with no valid point at all, the first 100 points of the chunk (ray 0, samples 0..99
-// in the reference's ray-major order) are evaluated anyway
-__global__ void k_quirk_first100(int* count, int* list, int R, int S) {
-    if (*count >= 1) return;
-    const int t = threadIdx.x;                     // launched with 128 threads
-    if (t < 100 && t < S) list[t] = t * R;         // slot of (ray 0, sample t)
-    if (t == 0) *count = (100 < S ? 100 : S);
-}
 
 // ---- one round of the hierarchical sampler (up_sample + sample_pdf, preceded by the cat_z_vals of the previous round; or that merge + render_core's head)
 // Round 3 ran three kernels per round (up-sample, merge, and the SDF network between them) that walked a ray's samples straight from the sample-major
@@ -96,11 +91,40 @@ struct RoundArgs {
     // upsample
     float inv_s; int n_imp;
     float* out_z; float* out_pts; float* out_sdf; uint8_t* out_msk; int* list; int* count;
+    int* done;                                       // optional zeroed counter: the round applies the reference's per-call quirk itself (round_epilogue)
     // finalize
     float sample_dist;
     float* mid_z; float* dists; float* pts; float* pm; float* o_sdf; float* grad; float* rgb; int defaults_everywhere;
     int merge_all_lists;                             // finalize + merge: also write the merged sdf / occupancy lists back (nobody reads them after the last round)
 };
+
+// The reference's two per-CALL rules on the emitted list, applied by the round kernel itself instead of a one-thread launch each (six launches of the
+// 22 of a 512-ray chunk): the workgroup that finishes LAST (a.done counts finished workgroups) sees the final count and
+//   up-sampling round  cat_z_vals (:137): the SDF of the new samples is evaluated only if MORE THAN ONE of them is inside the mask -> count <= 1 becomes 0;
+//   finalize           render_core (:222-223): with no occupied point at all the first 100 points of the chunk (ray 0, samples 0..99 in the
+//                      reference's ray-major order) are evaluated anyway.
+// Without a.done (the stage entry points) the launches k_quirk_min2 / nothing follow as before.
+template <int MODE>
+__device__ __forceinline__ void round_epilogue(const RoundArgs& a, int S) {
+    if (!a.done || MODE == RM_MERGE_ONLY) return;    // kernel argument: uniform over the launch
+    __shared__ int last;
+    __syncthreads();                                 // every append of this workgroup has returned its base
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(a.done, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const int c = atomicAdd(a.count, 0);
+    if (MODE == RM_UPSAMPLE) {
+        if (threadIdx.x == 0 && c <= 1) atomicExch(a.count, 0);
+    } else if (c < 1) {
+        const int n = 100 < S ? 100 : S;
+        for (int t = threadIdx.x; t < n; t += blockDim.x) a.list[t] = t * a.g.R;     // slot of (ray 0, sample t)
+        if (threadIdx.x == 0) atomicExch(a.count, n);
+    }
+}
 
 // ---- the same round as a STREAMING kernel: one lane per ray, the lists read from global memory ------------------------------------------------
 // Nothing is staged (an LDS-staged form -- 64 rays x 128 rows x 9 bytes per wave -- was measured this round: two waves per CU, 0.82 ms per round at
@@ -250,6 +274,7 @@ __global__ __launch_bounds__(256) void k_ray_stream(RoundArgs a, float* __restri
         }
         append_wave(bits, S, cnt, R, r, a.list, a.count);
     }
+    round_epilogue<MODE>(a, S);
 }
 
 // ---- the same round for SMALL batches: sixteen lanes per ray ---------------------------------------------------------------------------------------
@@ -442,6 +467,7 @@ __global__ __launch_bounds__(64) void k_ray_group(RoundArgs a) {
             }
         }
     }
+    round_epilogue<MODE>(a, S);
 }
 
 // render_core's compositing for small batches, sixteen lanes per ray: per-sample opacities and products in parallel, ONE lane runs the ordered
@@ -569,12 +595,12 @@ extern "C" {
 
 // ---- stage entry points (used by the parity tests; the orchestrator below calls the same kernels) -----------------
 static int ray_coarse_launch(const float* rays_o, const float* rays_d, int R, float near, float far, const float* near_ray, const float* far_ray, int S,
-                             const float* t_rand, float* z, float* pts, const float* maskvol, int D, uint8_t* msk, void* stream) {
+                             const float* t_rand, float* z, float* pts, const float* maskvol, int D, uint8_t* msk, void* stream, int* zero16 = nullptr) {
     O2345_REQUIRE(rays_o && rays_d && z && pts && R > 0 && S > 1, "ray_coarse: bad arguments");
     O2345_REQUIRE((near_ray != nullptr) == (far_ray != nullptr), "ray_coarse: per-ray near and far come together");
     RayGeom g{rays_o, rays_d, R};
     hipLaunchKernelGGL(k_ray_coarse, dim3(cdiv((long long)R * S, 256)), dim3(256), 0, (hipStream_t)stream, g, near, far, near_ray, far_ray, S, t_rand, z, pts,
-                       maskvol, D, msk);
+                       maskvol, D, msk, zero16);
     return check_launch("ray_coarse");
 }
 
@@ -740,8 +766,8 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
         if (io->sdf_mode == 2 && variant == 2) return o2345_sdf_grad_x3(io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, grad, stream);
         return o2345_sdf_mlp(variant, io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, nullptr, nullptr, grad, stream);
     };
-    O2345_HIP(hipMemsetAsync(count, 0, 16 * sizeof(int), s));          // every device-side counter of the call, once
-    if ((rc = ray_coarse_launch(io->rays_o, io->rays_d, R, io->near, io->far, io->near_ray, io->far_ray, NS, io->t_rand, z, pts, io->maskvol, io->D, msk, stream))) return rc;
+    // count[0..15]: every device-side counter of the call, cleared by the first kernel ([8..12]: finished workgroups of the five rounds, round_epilogue)
+    if ((rc = ray_coarse_launch(io->rays_o, io->rays_d, R, io->near, io->far, io->near_ray, io->far_ray, NS, io->t_rand, z, pts, io->maskvol, io->D, msk, stream, count))) return rc;
     // coarse SDF on ALL points (not masked, :525-528)
     if ((rc = sdf_eval(0, pts, nullptr, nullptr, (long long)NS * R, sdf, nullptr))) return rc;
     // four up-sampling rounds (:531-547); round i > 0 first merges round i - 1's samples (cat_z_vals) inside the same kernel
@@ -752,10 +778,9 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     ra.n_imp = (int)NI; ra.out_z = new_z; ra.out_pts = pts; ra.out_sdf = new_sdf; ra.out_msk = new_msk; ra.list = list;
     int cur = NS;
     for (int i = 0; i < 4; ++i) {
-        ra.S = cur; ra.n_new = i ? (int)NI : 0; ra.inv_s = 64.f * (float)(1 << i); ra.count = count + i;
-        if ((rc = ray_round_launch(RM_UPSAMPLE, ra, wbuf, stream))) return rc;
+        ra.S = cur; ra.n_new = i ? (int)NI : 0; ra.inv_s = 64.f * (float)(1 << i); ra.count = count + i; ra.done = count + 8 + i;
+        if ((rc = ray_round_launch(RM_UPSAMPLE, ra, wbuf, stream))) return rc;             // incl. cat_z_vals' "more than one point" rule (round_epilogue)
         cur += ra.n_new;
-        hipLaunchKernelGGL(k_quirk_min2, dim3(1), dim3(1), 0, s, count + i);
         if ((rc = sdf_eval(0, pts, list, count + i, 0, new_sdf, nullptr))) return rc;
     }
     count += 4;
@@ -763,10 +788,9 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     const float sample_dist = io->sample_dist > 0.f ? io->sample_dist : (io->far - io->near) / (float)NS;
     float* fpts = pts;   // reuse
     // the last cat_z_vals fused with render_core's head
-    ra.S = cur; ra.n_new = (int)NI; ra.count = count; ra.sample_dist = sample_dist;
+    ra.S = cur; ra.n_new = (int)NI; ra.count = count; ra.done = count + 8; ra.sample_dist = sample_dist;        // count was advanced by 4: slot 12
     ra.mid_z = io->mid_z; ra.dists = io->dists; ra.pts = fpts; ra.pm = io->pm; ra.o_sdf = io->sdf; ra.grad = io->grad; ra.rgb = io->rgb; ra.defaults_everywhere = 0;
-    if ((rc = ray_round_launch(RM_FINALIZE, ra, nullptr, stream))) return rc;
-    hipLaunchKernelGGL(k_quirk_first100, dim3(1), dim3(128), 0, s, count, list, R, (int)S);
+    if ((rc = ray_round_launch(RM_FINALIZE, ra, nullptr, stream))) return rc;               // incl. render_core's "first 100 points" rule (round_epilogue)
     // the list grouped by view-visibility signature (stable): the colour kernel then skips every (tile, view) pair in which no point sees the view instead of
     // 3/4 of them -- 40.0 -> 36.1 ms at 8 views, bit-identical results (csrc/list_sort.hip); only for lists long enough to pay for it (render_sorts_list)
     if (render_sorts_list(R, NS, NIMP, io->V)) {

@@ -397,11 +397,14 @@ def up_sample(rays_o, rays_d, z, sdf_v, n_imp, inv_s, maskvol, diag=None):
     return sample_pdf_det(z, alpha * T, n_imp, diag)
 
 
+CAT_Z_MIN_VALID = 1      # the reference's rule (:137).  Tests set 0 to show that a case they construct is SENSITIVE to the rule (never used otherwise)
+
+
 def cat_z(rays_o, rays_d, z, new_z, sdf_v, volume, maskvol, W):
     pts = (rays_o[:, None] + rays_d[:, None] * new_z[..., None]).reshape(-1, 3)
     m = mask_nearest(maskvol, pts) > 0
     new_sdf = torch.full((pts.shape[0],), 100.0)
-    if m.sum() > 1:                                          # quirk: skipped entirely if <= 1 valid point
+    if m.sum() > CAT_Z_MIN_VALID:                            # quirk: skipped entirely if <= 1 valid point
         new_sdf[m] = sdf(pts[m], volume, W)[0][:, 0]
     zz = torch.cat([z, new_z], 1)
     ss = torch.cat([sdf_v, new_sdf.reshape(new_z.shape)], 1)

@@ -76,12 +76,74 @@ def test_rays_that_miss_everything_and_single_ray():
     assert float(o["pm"].sum()) == 0 and int(o["color_mask"].sum()) == 0
     assert float((o["sdf"][:100, 0] != 100).float().mean()) > 0.9          # ray 0's first 100 samples were evaluated anyway (:222-223)
     assert float((o["sdf"][:, 1:] == 100).float().mean()) == 1.0
+    # the same rule in the large-batch form of the round kernels (one lane per ray, >= O2345_RAY_STREAM_MIN rays): applied by the workgroup that finishes last
+    n_big = 4096 + 37
+    ob = ops.render_rays(scene, ro[:1].repeat(n_big, 1).contiguous(), rd[:1].repeat(n_big, 1).contiguous(), 0.1, 2.0, 64, 64, 7.4, 1.0, 1.0, qcam, want_scalars=True)
+    assert float(ob["pm"].sum()) == 0 and torch.allclose(ob["color"], torch.ones(n_big, 3, device=dev))
+    assert float((ob["sdf"][:100, 0] != 100).float().mean()) > 0.9 and float((ob["sdf"][:, 1:] == 100).float().mean()) == 1.0
+    assert torch.equal(ob["sdf"][:, 0], o["sdf"][:, 0]) and float(ob["scalars"][3]) == 100.0          # evaluated points: the 100 forced ones
     # a single ray through the object equals the same ray inside a batch
     ro1, rd1 = torch.from_numpy(s["sc"]["query_c2w"][:3, 3].copy())[None].to(dev), torch.tensor([[0.0, 0.0, 1.0]], device=dev)
     near, far = float(s["sc"]["query_near_far"][0]), float(s["sc"]["query_near_far"][1])
     a = ops.render_rays(scene, ro1, rd1, near, far, 64, 64, 7.4, 1.0, 1.0, qcam)
     b = ops.render_rays(scene, ro1.repeat(5, 1), rd1.repeat(5, 1), near, far, 64, 64, 7.4, 1.0, 1.0, qcam)
     assert torch.allclose(a["color"][0], b["color"][3], atol=1e-6) and torch.allclose(a["depth"][0], b["depth"][3], atol=1e-6)
+
+
+@pytest.mark.parametrize("form", ["group", "stream"])
+def test_cat_z_vals_rule_for_a_single_occupied_new_sample(form, lib_instance):
+    """cat_z_vals (:137) evaluates the SDF of a round's new samples only if MORE THAN ONE of them is inside the mask; otherwise all sixteen keep 100.
+    The render call applies the rule inside the round kernel (the workgroup that finishes last, csrc/render.hip round_epilogue).  Constructed case: the
+    mask holds ONE voxel inside the object (SDF < 0) and one ray crosses it along x with 16 coarse samples (spacing 0.127 > the voxel's 0.1): one
+    coarse sample and, in every round, exactly one new sample lie in the voxel.  The oracle WITHOUT the rule puts its samples elsewhere (lists differ
+    by ~0.6), so agreement with the oracle proper shows that the rule fired -- in both forms of the round kernels."""
+    from scene_util import color_t
+    lib_instance({"O2345_RAY_STREAM_MIN": "1" if form == "stream" else "1000000"})
+    s = small_scene()
+    scene = _tiny_scene(s)
+    sc, D = s["sc"], s["D"]
+    Wt = sdfW_t(s["sdfW"])
+    c = (2 * torch.arange(D) + 1) / D - 1                                     # voxel centres of the nearest-mask lookup
+    ctr = torch.stack(torch.meshgrid(c, c, c, indexing="ij"), -1).reshape(-1, 3)
+    inside = torch.nonzero(O.sdf(ctr, s["dense"][0], Wt)[0][:, 0].reshape(D, D, D) < -0.05)
+    assert inside.shape[0] >= 4
+    qcam = torch.from_numpy(sc["query_c2w"][:3, 3].copy())
+    a = dict(volume=s["dense"][0], W=Wt, RW=color_t(s["color_sd"]), variance=torch.tensor(0.2), feat_maps=torch.from_numpy(s["fmaps"]),
+             color_maps=torch.from_numpy(sc["images"]), w2cs=torch.from_numpy(sc["w2cs"]), K=torch.from_numpy(sc["intrinsics"]), img_wh=(s["W"], s["H"]),
+             query_c2w=torch.from_numpy(sc["query_c2w"]))
+    inv_s = float(torch.exp(a["variance"] * 10.0))
+
+    def oracle(mask, ro, rd, min_valid):
+        O.CAT_Z_MIN_VALID = min_valid
+        try:
+            trace = []
+            r = O.render(ro, rd, torch.tensor(0.1), torch.tensor(2.0), a["volume"], mask, a["W"], a["RW"], a["variance"], a["feat_maps"], a["color_maps"],
+                         a["w2cs"], a["K"], a["img_wh"], a["query_c2w"], n_samples=16, n_importance=64, trace=trace)
+        finally:
+            O.CAT_Z_MIN_VALID = 1
+        return r, trace
+
+    fired = 0
+    for vi, off in ((0, 0.0), (inside.shape[0] // 3, 0.02), (2 * inside.shape[0] // 3, -0.03), (inside.shape[0] - 1, 0.0)):
+        ix, iy, iz = (int(v) for v in inside[vi])
+        mask = torch.zeros(D, D, D)
+        mask[ix, iy, iz] = 1
+        ro = torch.tensor([[float(c[ix]) - 1.0 + off, float(c[iy]), float(c[iz])]])
+        rd = torch.tensor([[1.0, 0.0, 0.0]])
+        ref, trace = oracle(mask, ro, rd, 1)
+        per_round = [int(O.mask_nearest(mask, (ro[:, None] + rd[:, None] * t["new_z"][..., None]).reshape(-1, 3)).sum()) for t in trace]
+        without, _ = oracle(mask, ro, rd, 0)
+        sensitive = float((ref["z_vals"] - without["z_vals"]).abs().max())
+        sm = dict(scene, maskvol=mask.reshape(-1).contiguous().to(dev))
+        o = ops.render_rays(sm, ro.to(dev), rd.to(dev), 0.1, 2.0, 16, 64, inv_s, 1.0, 1.0, qcam.to(dev), want_z=True)
+        dz = float((o["z_vals"].t().cpu() - ref["z_vals"]).abs().max())
+        print(f"[{form}] voxel {ix, iy, iz} offset {off}: occupied new samples per round {per_round}, lists differ by {dz:.2e} from the oracle, "
+              f"{sensitive:.2e} between the oracle with and without the rule")
+        assert dz < 2e-4
+        assert (o["color"].cpu() - ref["color_fine"]).abs().max() < 1e-3 and (o["depth"].cpu()[:, None] - ref["depth"]).abs().max() < 1e-3
+        if 1 in per_round and sensitive > 0.1:
+            fired += 1
+    assert fired >= 2, "the constructed cases must exercise the rule"
 
 
 def test_zero_points_and_tiny_grids():
