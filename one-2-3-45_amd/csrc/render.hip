@@ -104,18 +104,19 @@ struct RoundArgs {
 //   finalize           render_core (:222-223): with no occupied point at all the first 100 points of the chunk (ray 0, samples 0..99 in the
 //                      reference's ray-major order) are evaluated anyway.
 // Without a.done (the stage entry points) the launches k_quirk_min2 / nothing follow as before.
+// Ordering without fences: `count` and `done` are only ever touched by agent-scope atomic read-modify-writes, which are performed at the device's
+// coherent point; a workgroup's appends have RETURNED (their result is consumed) before its barrier, its increment of `done` is issued after the barrier,
+// and the last workgroup reads `count` (an atomic again) after its own increment has returned -- so every append precedes that read.  An agent-scope
+// fence (__threadfence) here is an L2 write-back of everything the kernel has written on this multi-XCD part: measured + 31 / 40 / 72 us per launch
+// at 262,144 rays (profiles/NOTES.md), for an ordering the atomics already have.
 template <int MODE>
 __device__ __forceinline__ void round_epilogue(const RoundArgs& a, int S) {
     if (!a.done || MODE == RM_MERGE_ONLY) return;    // kernel argument: uniform over the launch
     __shared__ int last;
     __syncthreads();                                 // every append of this workgroup has returned its base
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(a.done, 1) == (int)gridDim.x - 1;
-    }
+    if (threadIdx.x == 0) last = atomicAdd(a.done, 1) == (int)gridDim.x - 1;
     __syncthreads();
     if (!last) return;
-    __threadfence();
     const int c = atomicAdd(a.count, 0);
     if (MODE == RM_UPSAMPLE) {
         if (threadIdx.x == 0 && c <= 1) atomicExch(a.count, 0);
