@@ -30,6 +30,45 @@ def test_cabi_exports_every_declared_symbol():
     assert rc != 0 and b"null pointer" in lib.o2345_last_error()
 
 
+def test_render_call_validates_its_arguments_before_touching_the_device():
+    """o2345_render_rays rejects what it cannot do with a message that says why (the checks run on the host, ahead of every HIP call): the reference's
+    n_importance is split into four rounds, sample slots are 32-bit, the caller sizes the workspace with o2345_render_workspace_bytes."""
+    import ctypes
+    L = importlib.import_module("one-2-3-45_amd._lib")
+    lib = L.lib()
+    lib.o2345_render_workspace_bytes.restype = ctypes.c_size_t
+    ws_bytes = lib.o2345_render_workspace_bytes(512, 64, 64, 8)
+    assert ws_bytes >= 512 * 128 * (4 * 2 + 12 + 4 + 1)                     # z, sdf, pts, list, occupancy for every sample slot
+    assert lib.o2345_render_workspace_bytes(262144, 64, 64, 8) > lib.o2345_render_workspace_bytes(262144, 64, 64, 40)      # > 32 views: no list sort, no sort buffers
+    dummy = ctypes.c_void_p(256)                                            # a non-null pointer that is never dereferenced: every call below fails in the checks
+
+    def call(**kw):
+        io = L.RenderIO()
+        io.R, io.n_samples, io.n_importance, io.V, io.sdf_mode = 512, 64, 64, 8, 2
+        io.color_x3_blob = 256
+        for k, v in kw.items():
+            setattr(io, k, v)
+        rc = lib.o2345_render_rays(ctypes.byref(io), dummy, ctypes.c_size_t(ws_bytes), None)
+        return rc, lib.o2345_last_error()
+
+    rc, msg = call(n_importance=62)
+    assert rc != 0 and b"multiple of 4" in msg
+    rc, msg = call(R=1 << 24, n_samples=128, n_importance=128)
+    assert rc != 0 and b"2^31" in msg
+    rc, msg = call(n_samples=200, n_importance=64, R=4)
+    assert rc != 0 and b"at most 256 samples" in msg
+    rc, msg = call(color_x3_blob=None)
+    assert rc != 0 and b"colour network blob" in msg
+    rc, msg = call(sdf_mode=1)
+    assert rc != 0 and b"SDF mode 1" in msg
+    io = L.RenderIO()
+    io.R, io.n_samples, io.n_importance, io.V, io.sdf_mode = 512, 64, 64, 8, 2
+    io.color_x3_blob = 256
+    rc = lib.o2345_render_rays(ctypes.byref(io), dummy, ctypes.c_size_t(ws_bytes - 1), None)
+    assert rc != 0 and b"workspace too small" in lib.o2345_last_error()
+    assert lib.o2345_render_rays(None, dummy, ctypes.c_size_t(ws_bytes), None) != 0 and b"null pointer" in lib.o2345_last_error()
+
+
 def test_render_io_has_one_declaration_and_the_binding_checks_it(tmp_path):
     """O2345RenderIO is declared in include/o2345.h only: csrc/ compiles that header (common.h includes it), the ctypes Structure is generated from its
     text, and the loaded library's own sizeof / offsetof table is compared at load time.  A field added to ONE side only must fail loudly."""
