@@ -137,6 +137,30 @@ def render(wt, vol, proj, cam_pos, rays_o, rays_d, near, far, query_cam, n_sampl
 
 
 @torch.no_grad()
+def render_scene_split(wt, imgs, affine_mats, origin, D, voxel_size, proj, cam_pos, rays_o, rays_d, near, far, query_cam, src=0,
+                       keys=("color", "depth", "weights_sum", "color_mask"), **render_kw):
+    """ONE image rendered by all ranks of the process group (intra-scene split; single-scene latency instead of scene throughput).
+    ``imgs`` [V,3,H,W]: the scene's source images on rank ``src`` (None elsewhere) -- one broadcast; every rank builds the volume itself and renders a
+    contiguous block of the rays (sharding.ray_block); one all-gather returns ``keys`` of pipeline.render for ALL rays on every rank.  A render call's
+    results do not depend on how the rays are batched (tests/test_gpu_parity.py::test_chunked_render_equals_one_call), so the result equals the
+    one-GPU call bit for bit wherever the reference's per-call rules cannot fire (a block without any occupied sample).  Without a process group this
+    is build_volume + render."""
+    from . import sharding as sh
+    dev = rays_o.device
+    imgs = sh.broadcast_tensor(imgs, src=src, device=dev)
+    vol = build_volume(wt, imgs, affine_mats, origin, D, voxel_size)
+    rank, world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) if torch.distributed.is_initialized() else (0, 1)
+    lo, hi, per = sh.ray_block(rays_o.shape[0], rank, world)
+    if hi > lo:
+        o = render(wt, vol, proj, cam_pos, rays_o[lo:hi].contiguous(), rays_d[lo:hi].contiguous(), near, far, query_cam, **render_kw)
+        block = {k: o[k] for k in keys}
+    else:                                                # more ranks than 64-ray blocks: this rank contributes nothing
+        o = render(wt, vol, proj, cam_pos, rays_o[:1].contiguous(), rays_d[:1].contiguous(), near, far, query_cam, **render_kw)
+        block = {k: o[k][:0] for k in keys}
+    return sh.gather_ray_blocks(block, rays_o.shape[0], per, device=dev), vol
+
+
+@torch.no_grad()
 def extract_mesh(wt, vol, proj, cam_pos, resolution, return_index_verts=False):
     """extract_fields + marching cubes + vertex colouring (trainer_generic.py:1309-1363), all on the device."""
     prec = wt.sdf_precision

@@ -101,3 +101,45 @@ def test_two_rank_weight_broadcast_and_per_rank_gather():
     assert res[0][1]["variance_network_lod0"]["variance"][0] == () and abs(res[0][1]["variance_network_lod0"]["variance"][2] - 0.37) < 1e-7
     assert res[0][1]["rendering_network_lod0"]["base_fc.0.weight"][0] == (64, 193)
     assert res[0][2] == res[1][2] == [{"rank": 0, "ms": 10.0}, {"rank": 1, "ms": 11.0}]
+
+
+def _split_worker(rank, world, port, q, n_rays):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sh = importlib.import_module("one-2-3-45_amd.sharding")
+    sh.init("gloo")
+    # the exchange step in: only rank 0 holds the scene's images
+    imgs = torch.arange(2 * 3 * 5 * 7, dtype=torch.float32).reshape(2, 3, 5, 7) * 0.37 if rank == 0 else None
+    imgs = sh.broadcast_tensor(imgs, src=0)
+    lo, hi, per = sh.ray_block(n_rays, rank, world)
+    r = torch.arange(lo, hi, dtype=torch.float32)
+    # "rendered" per-ray outputs of this rank's block: values that identify the ray, in the types pipeline.render returns
+    block = {"color": torch.stack([r, r * 0.5 + 1e-3, -r], 1), "depth": r * 1.0000001 + 0.25, "color_mask": (r.long() % 3 == 0).to(torch.uint8)}
+    full = sh.gather_ray_blocks(block, n_rays, per)
+    q.put((rank, (lo, hi, per), float(imgs.double().sum()), tuple(imgs.shape), {k: (tuple(v.shape), str(v.dtype), v.double().sum().item()) for k, v in full.items()},
+           bool(torch.equal(full["depth"], torch.arange(n_rays, dtype=torch.float32) * 1.0000001 + 0.25)),
+           bool(torch.equal(full["color_mask"], (torch.arange(n_rays) % 3 == 0).to(torch.uint8)))))
+    sh.shutdown()
+
+
+def test_two_rank_ray_split_of_one_image():
+    """SURVEY 8e's optional intra-scene split: the images go out in one broadcast, contiguous ray blocks (multiples of a wavefront) are rendered per
+    rank, one all-gather returns every ray to every rank in ray order, bit-exact -- on gloo, with a ray count that does not divide."""
+    sh = importlib.import_module("one-2-3-45_amd.sharding")
+    for n, w in ((1000, 2), (262144, 8), (65, 4), (1, 3), (4096, 1)):
+        bl = [sh.ray_block(n, r, w) for r in range(w)]
+        assert bl[0][0] == 0 and bl[-1][1] == n and all(bl[i][1] == bl[i + 1][0] for i in range(w - 1)) and all(b[2] % 64 == 0 and b[1] - b[0] <= b[2] for b in bl)
+    world, port, n_rays = 2, _free_port(), 1000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_split_worker, args=(r, world, port, q, n_rays)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    assert res[0][1] == (0, 512, 512) and res[1][1] == (512, 1000, 512)
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] == (2, 3, 5, 7)                 # the same images on both ranks
+    assert res[0][4] == res[1][4] and res[0][4]["color"][0] == (1000, 3) and res[0][4]["color_mask"][1] == "torch.uint8"
+    assert all(r[5] and r[6] for r in res)                                                   # every ray, in order, bit-exact
+    # without a process group the helpers are the identity
+    blk = {"depth": torch.arange(5.0)}
+    assert sh.broadcast_tensor(blk["depth"]) is blk["depth"] and sh.gather_ray_blocks(blk, 5, 64)["depth"] is blk["depth"]
