@@ -73,11 +73,14 @@ class SceneWeights:
 
 
     @classmethod
-    def from_checkpoint(cls, device, path, broadcast=False, sdf_precision=None, color_precision=None):
+    def from_checkpoint(cls, device, path, broadcast=False, sdf_precision=None, color_precision=None, allow_pickle=None):
         """Every rank builds its weights from ONE checkpoint file in the reference's format (exp_runner_generic_blender_val.py:514-541: keys
         ``sdf_network_lod0``, ``rendering_network_lod0``, ``variance_network_lod0``, ``pyramid_feature_network``).  Default: each rank reads the file
         (< 4 MB); ``broadcast=True``: rank 0 OF THE PROCESS GROUP reads it and the state dicts reach the other ranks through
-        sharding.broadcast_state_dicts (one RCCL broadcast) -- ``path`` may then be None on the other ranks; needs an initialised process group."""
+        sharding.broadcast_state_dicts (one RCCL broadcast) -- ``path`` may then be None on the other ranks; needs an initialised process group.
+        The file is read with torch's restricted unpickler.  A checkpoint that needs the full unpickler (optimizer state with numpy scalars, as the
+        reference's own trainer writes) executes arbitrary code from the file when loaded: that is opt-in -- ``allow_pickle=True`` or O2345_ALLOW_PICKLE=1
+        -- for files you trust, never a silent fallback."""
         import torch.distributed as dist
         from . import sharding
         names = ("sdf_network_lod0", "rendering_network_lod0", "variance_network_lod0", "pyramid_feature_network")
@@ -85,9 +88,18 @@ class SceneWeights:
             raise RuntimeError("SceneWeights.from_checkpoint(broadcast=True) needs an initialised torch.distributed process group (sharding.init)")
         state = None
         if not broadcast or dist.get_rank() == 0:
+            import os
+            if allow_pickle is None:
+                allow_pickle = os.environ.get("O2345_ALLOW_PICKLE", "0") not in ("", "0")
             try:                                   # only float tensors are kept, so the restricted unpickler is enough for a well-formed checkpoint
                 ck = torch.load(path, map_location="cpu", weights_only=True)
-            except Exception:                      # checkpoints that carry optimizer / numpy scalars need the full unpickler (the reference's own loader uses it)
+            except Exception as e:                 # checkpoints that carry optimizer / numpy scalars need the full unpickler (the reference's own loader uses it)
+                if not allow_pickle:
+                    raise RuntimeError(f"o2345 SceneWeights.from_checkpoint: {path!r} does not load with the restricted unpickler ({type(e).__name__}: {e}); "
+                                       "pass allow_pickle=True (or O2345_ALLOW_PICKLE=1) only for a checkpoint you trust -- the full unpickler runs code "
+                                       "from the file") from e
+                import warnings
+                warnings.warn(f"o2345: loading {path!r} with the FULL unpickler (allow_pickle): code in the file is executed")
                 ck = torch.load(path, map_location="cpu", weights_only=False)
             state = {n: {k: v for k, v in ck[n].items() if torch.is_tensor(v) and v.is_floating_point()} for n in names}
         if broadcast:
@@ -151,11 +163,14 @@ def render_scene_split(wt, imgs, affine_mats, origin, D, voxel_size, proj, cam_p
     vol = build_volume(wt, imgs, affine_mats, origin, D, voxel_size)
     rank, world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) if torch.distributed.is_initialized() else (0, 1)
     lo, hi, per = sh.ray_block(rays_o.shape[0], rank, world)
+    R_all = rays_o.shape[0]
+    per_ray = lambda a, b: {k: (v[a:b].contiguous() if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == R_all else v)     # t_rand [R, n_samples] (perturb > 0)
+                            for k, v in render_kw.items()}                                                                  # follows its rays
     if hi > lo:
-        o = render(wt, vol, proj, cam_pos, rays_o[lo:hi].contiguous(), rays_d[lo:hi].contiguous(), near, far, query_cam, **render_kw)
+        o = render(wt, vol, proj, cam_pos, rays_o[lo:hi].contiguous(), rays_d[lo:hi].contiguous(), near, far, query_cam, **per_ray(lo, hi))
         block = {k: o[k] for k in keys}
     else:                                                # more ranks than 64-ray blocks: this rank contributes nothing
-        o = render(wt, vol, proj, cam_pos, rays_o[:1].contiguous(), rays_d[:1].contiguous(), near, far, query_cam, **render_kw)
+        o = render(wt, vol, proj, cam_pos, rays_o[:1].contiguous(), rays_d[:1].contiguous(), near, far, query_cam, **per_ray(0, 1))
         block = {k: o[k][:0] for k in keys}
     return sh.gather_ray_blocks(block, rays_o.shape[0], per, device=dev), vol
 

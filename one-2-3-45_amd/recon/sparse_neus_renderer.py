@@ -12,9 +12,10 @@ from .sparse_sdf_network import _attr_cache, channel_last
 def _scene_maps(feature_maps, color_maps, w2cs, intrinsics):
     """-> (colour map [V,H,W,64] = rgb | features | pad, proj [V,3,4], cam_pos [V,3]) of the scene's source views (models/projector.py:96-228 gathers from
     them); cached per tensor object + version."""
-    cm = _attr_cache(feature_maps, "_o2345_cmaps", (id(color_maps), color_maps._version),
+    # (the partner tensor enters the key by object, storage and version: a bare id() can be reused by a later temporary with other content)
+    cm = _attr_cache(feature_maps, "_o2345_cmaps", (id(color_maps), color_maps.data_ptr(), color_maps._version),
                      lambda: ops.pack_color_maps(feature_maps.detach().contiguous().float(), color_maps.detach().contiguous().float()))
-    proj, cam_pos = _attr_cache(w2cs, "_o2345_cam", (id(intrinsics), intrinsics._version),
+    proj, cam_pos = _attr_cache(w2cs, "_o2345_cam", (id(intrinsics), intrinsics.data_ptr(), intrinsics._version),
                                 lambda: ops.camera_terms(intrinsics.detach(), w2cs.detach()))
     return cm, proj, cam_pos
 
@@ -150,9 +151,11 @@ class SparseNeuSRenderer(nn.Module):
                             _attr_cache(query_c2w, "_o2345_qcam", (), lambda: query_c2w.reshape(-1, 4, 4)[0, :3, 3].contiguous().float()),
                             t_rand=t_rand, sample_dist=sample_dist, want_scalars=True)
         S = self.n_samples + self.n_importance
-        # the 1,024 random points of every call (:579-582): drawn on the device generator like the reference's torch.rand(...) * 2 - 1, evaluated by the
+        # the 1,024 random points of every call (:606): torch.rand([1024, 3]) on the HOST generator -- the second and last host draw of a call, after
+        # t_rand -- moved to the device and mapped to (-1, 1) there, exactly the reference's expression: under one torch.manual_seed the host stream
+        # advances by R * n_samples + 3,072 numbers per call, so every later chunk of an image draws the reference's jitter too.  Evaluated by the
         # SDF-only kernel (the reference's sdf() also returns 128 features nobody reads here)
-        pts_random = torch.empty(1024, 3, device=dev).uniform_(-1.0, 1.0)
+        pts_random = torch.rand([1024, 3], pin_memory=dev.type == "cuda").to(dev, non_blocking=True) * 2 - 1
         sdf_random = ops.sdf_mlp(scene["sdf_blob"], scene["vol_cl"], pts_random, variant=0)["sdf"][:, None]
         sc = o["scalars"]                            # [alpha_sum.mean(), alpha_sum.sum() / (R S), gradient error, evaluated points]: one tiny kernel inside the call
         return {"depth": o["depth"][:, None], "color_fine": o["color"], "color_fine_mask": o["color_mask"].view(torch.bool)[:, None], "color_outside": None,

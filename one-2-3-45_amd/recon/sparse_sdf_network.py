@@ -82,7 +82,7 @@ class LatentSDFLayer(nn.Module):
 
     def blob(self):
         ps = self._params()
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        key = tuple((id(p), p.data_ptr(), p._version) for p in ps)
         if self._blob is None or key != self._blob_key:
             W = weights.sdf_weights_from_state_dict({k: v.detach() for k, v in self.state_dict().items()}, "")
             self._blob = torch.from_numpy(weights.packed_sdf_blob(W)).to(ps[0].device)
@@ -134,14 +134,9 @@ class SparseSdfNetwork(nn.Module):
         self.sdf_layer = LatentSDFLayer(d_in=3, d_out=hidden_dim + 1, d_hidden=hidden_dim, n_layers=num_sdf_layers, multires=multires,
                                         geometric_init=True, weight_norm=True, activation=activation, d_conditional_feature=16)
         self._lattice = {}
-        self._costreg_params = None
         # weights are packed for the kernels when they are LOADED (the runner loads its checkpoint before the first timed call,
         # exp_runner_generic_blender_val.py:485-512), not inside the first query
         self.register_load_state_dict_post_hook(_prepack_after_load)
-
-    def _apply(self, fn, *a, **k):
-        self._costreg_params = None
-        return super()._apply(fn, *a, **k)
 
     def prepack(self, resolutions=()):
         """Pack every parameter for the kernels now (operand blobs, packed sparse CNN, convolution weights, optional layer-0 tables of the extraction
@@ -171,10 +166,15 @@ class SparseSdfNetwork(nn.Module):
 
     def _costreg(self, device):
         """The packed sparse CNN of the current parameters (re-packed only when a parameter changes)."""
-        if self._costreg_params is None:
-            self._costreg_params = [p for _, p in sorted(self.sparse_costreg_net.state_dict(keep_vars=True).items())]
-        ps = self._costreg_params
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in ps)
+        # the CURRENT parameter objects on every call (10 blocks x (kernel, BN weight, BN bias): a cached list goes stale when load_state_dict(assign=True)
+        # or a direct assignment replaces the Parameter objects); read from the modules' own tables, no walk over the module tree
+        ps = []
+        for name, _, _ in COSTREG_LAYERS:
+            net = self.sparse_costreg_net._modules[name]._modules["net"]._modules
+            ps.append(net["0"]._parameters["kernel"])
+            ps.append(net["1"]._parameters["weight"])
+            ps.append(net["1"]._parameters["bias"])
+        key = (str(device),) + tuple((id(p), p.data_ptr(), p._version) for p in ps)
         if getattr(self, "_costreg_key", None) != key:
             sd = {k: v.detach() for k, v in self.sparse_costreg_net.state_dict().items()}
             self._costreg_net, self._costreg_key = CostRegNet(sd, device), key

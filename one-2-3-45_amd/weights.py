@@ -38,6 +38,9 @@ def _layout_version():
     if _LAYOUT_VERSION is None:
         h = _hasher()
         h.update(open(os.path.abspath(__file__), "rb").read())
+        hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "o2345.h")
+        if os.path.exists(hdr):              # the C side's blob layouts change with the ABI: its header (O2345_ABI_VERSION, the blob-size contracts) is part of the key
+            h.update(open(hdr, "rb").read())
         _LAYOUT_VERSION = h.hexdigest()
     return _LAYOUT_VERSION
 
@@ -49,13 +52,16 @@ def cache_dir():
     return None if d in ("", "off") else d
 
 
-def cached_pack(kind, arrays, pack):
-    """``pack()`` -> numpy blob, memoised by the content of ``arrays`` (list of numpy arrays, the packer's inputs in a fixed order)."""
+def cached_pack(kind, arrays, pack, expect_size=None, names=()):
+    """``pack()`` -> numpy blob, memoised by the content of ``arrays`` (list of numpy arrays, the packer's inputs in a fixed order; ``names``: their
+    state-dict keys, hashed too).  A file from the disk cache is only trusted when it is a 1-D float32 array of ``expect_size`` elements (the kernels read
+    the blob at fixed offsets: a short, stale or planted file must never reach the device) -- anything else is recomputed and rewritten."""
     if not CACHE_ENABLED:
         return pack()
     h = _hasher()
     h.update(kind.encode())
     h.update(_layout_version().encode())
+    h.update(repr(tuple(names)).encode())
     for a in arrays:
         a = np.ascontiguousarray(a)
         h.update(str((a.dtype.str, a.shape)).encode())
@@ -69,8 +75,11 @@ def cached_pack(kind, arrays, pack):
     blob = None
     if path and os.path.exists(path):
         try:
-            blob = np.load(path)
+            blob = np.load(path, allow_pickle=False)
         except Exception:                    # a truncated file from a killed process: recompute and rewrite
+            blob = None
+        if blob is not None and not (isinstance(blob, np.ndarray) and blob.dtype == np.float32 and blob.ndim == 1 and blob.size > 0
+                                     and (expect_size is None or blob.size == int(expect_size)) and bool(np.isfinite(blob).all())):
             blob = None
     if blob is None:
         blob = pack()
@@ -92,25 +101,26 @@ def _sd_arrays(sd):
 
 
 def packed_sdf_blob(W):
-    return cached_pack("sdf", [W[k] for k in sorted(W)], lambda: pack_sdf_blob(W))
+    return cached_pack("sdf", [W[k] for k in sorted(W)], lambda: pack_sdf_blob(W), SDF_BLOB_FLOATS, sorted(W))
 
 
 def packed_color_mfma_blob(sd):
-    return cached_pack("color_mfma", _sd_arrays(sd), lambda: pack_color_mfma_blob(sd))
+    return cached_pack("color_mfma", _sd_arrays(sd), lambda: pack_color_mfma_blob(sd), CM_BLOB_FLOATS, sorted(sd))
 
 
 def packed_color_x3_blob(sd):
-    return cached_pack("color_x3", _sd_arrays(sd), lambda: pack_color_x3_blob(sd))
+    return cached_pack("color_x3", _sd_arrays(sd), lambda: pack_color_x3_blob(sd), CX_BLOB_FLOATS, sorted(sd))
 
 
 def packed_sparse_conv_x3(K):
     Kn = np.asarray(K.detach().cpu().numpy() if hasattr(K, "detach") else K, np.float32)
-    return cached_pack("sparse_x3", [Kn], lambda: pack_sparse_conv_x3(Kn))
+    return cached_pack("sparse_x3", [Kn], lambda: pack_sparse_conv_x3(Kn),
+                       27 * Kn.shape[1] * ((Kn.shape[2] + 31) // 32) * 32)      # hi | lo f16 halves of [27][cin][cout padded to 32] = that many floats
 
 
 def packed_sdf_grid_tables(W, R):
     key = [W["w0"], W["b0"], np.asarray([int(R)])]
-    both = cached_pack("sdf_tabs", key, lambda: np.concatenate([a.reshape(-1) for a in sdf_grid_tables(W, R)]))
+    both = cached_pack("sdf_tabs", key, lambda: np.concatenate([a.reshape(-1) for a in sdf_grid_tables(W, R)]), 3 * int(R) * 128 + 128, ("w0", "b0", "R"))
     return both[:3 * int(R) * 128].reshape(3, int(R), 128), both[3 * int(R) * 128:]
 
 

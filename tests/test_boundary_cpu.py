@@ -221,3 +221,38 @@ def test_invalidate_packed_drops_every_weight_cache():
     net[0].conv0[0].conv._o2345_packed_key = ("stale",)
     fn.invalidate_packed(net)
     assert all(getattr(m, k, None) is None for m in net.modules() for k in keys)
+
+
+def test_replaced_parameter_objects_are_repacked():
+    """load_state_dict(assign=True) / `m.weight = nn.Parameter(...)` REPLACE the Parameter objects.  The packed operand caches (colour blobs, SDF blob,
+    packed sparse CNN) must follow the modules' CURRENT parameters -- a cached parameter list keyed on the dead objects served stale weights."""
+    import torch
+    sdfm = importlib.import_module("one-2-3-45_amd.recon.sparse_sdf_network")
+    renm = importlib.import_module("one-2-3-45_amd.recon.rendering_network")
+    torch.manual_seed(0)
+    rn = renm.GeneralRenderingNetwork(in_geometry_feat_ch=16)
+    assert sorted(id(p) for p in rn._params()) == sorted(id(p) for p in rn.parameters())          # the fixed-order list is complete
+    b0 = rn.x3_blob().clone()
+    torch.manual_seed(1)
+    other = renm.GeneralRenderingNetwork(in_geometry_feat_ch=16)
+    rn.load_state_dict(other.state_dict(), assign=True)
+    assert torch.equal(rn.x3_blob(), other.x3_blob()) and not torch.equal(rn.x3_blob(), b0)
+    rn.rgb_fc[4].weight = torch.nn.Parameter(rn.rgb_fc[4].weight.detach() * 2)                    # direct replacement of one object
+    fresh = renm.GeneralRenderingNetwork(in_geometry_feat_ch=16)
+    fresh.load_state_dict(rn.state_dict())
+    assert torch.equal(rn.x3_blob(), fresh.x3_blob()) and torch.equal(rn.mfma_blob(), fresh.mfma_blob())
+    # SDF layer + sparse CNN
+    torch.manual_seed(2)
+    sn = sdfm.SparseSdfNetwork(lod=0, ch_in=56, voxel_size=0.1, vol_dims=[8, 8, 8], regnet_d_out=16)
+    torch.manual_seed(3)
+    so = sdfm.SparseSdfNetwork(lod=0, ch_in=56, voxel_size=0.1, vol_dims=[8, 8, 8], regnet_d_out=16)
+    so.sdf_layer.lin1.weight_v.data[:, 128:] += 0.05
+    b0 = sn.sdf_layer.blob().clone()
+    c0 = sn._costreg("cpu")
+    assert sn._costreg("cpu") is c0                                                               # unchanged parameters: no re-pack
+    sn.load_state_dict(so.state_dict(), assign=True)
+    assert torch.equal(sn.sdf_layer.blob(), so.sdf_layer.blob()) and not torch.equal(sn.sdf_layer.blob(), b0)
+    c1 = sn._costreg("cpu")
+    assert c1 is not c0
+    for name in c1.p:
+        assert all(torch.equal(a, b) for a, b in zip(c1.p[name], so._costreg("cpu").p[name]))

@@ -93,6 +93,18 @@ def test_cached_pack_is_content_keyed(pkg, tmp_path, monkeypatch):
         f.truncate(100)
     e = W.packed_color_x3_blob(sd)
     assert len(calls) == 3 and np.array_equal(e, a)
+    # a well-formed .npy of the wrong size / dtype (stale layout, planted file) is not trusted either: the kernels read the blob at fixed offsets
+    for bad in (a[:-8].copy(), a.astype(np.float64), np.full_like(a, np.nan)):
+        W._MEM_CACHE.clear()
+        np.save(os.path.join(tmp_path, files[0]), bad)
+        n = len(calls)
+        e = W.packed_color_x3_blob(sd)
+        assert len(calls) == n + 1 and e.dtype == np.float32 and np.array_equal(e, a)
+    # equal arrays under other key names are a different key
+    W._MEM_CACHE.clear()
+    k1 = W.cached_pack("t", [np.ones(3, np.float32)], lambda: np.zeros(4, np.float32), 4, ("a",))
+    k2 = W.cached_pack("t", [np.ones(3, np.float32)], lambda: np.ones(4, np.float32), 4, ("b",))
+    assert not np.array_equal(k1, k2)
     monkeypatch.setenv("O2345_CACHE_DIR", "off")
     W._MEM_CACHE.clear()
     assert W.cache_dir() is None and np.array_equal(W.packed_sdf_blob(W.init_sdf_weights(1)), W.pack_sdf_blob(W.init_sdf_weights(1)))
