@@ -318,6 +318,7 @@ def cpu_baseline_and_parity(wt, vol, inp, D, n_rays, budget_s=15.0):
     sampler stage with identical inputs, everything downstream on the HIP path's own sample lists (all rays), end-to-end distribution."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fullsize_util as FU                                     # test infrastructure (oracle side of the comparison)
+    FU.CHUNK = 512                                                  # the runner's ray batch (trainer_generic.py:503) on BOTH sides: the oracle is timed the way the reference
     torch.set_num_threads(min(32, os.cpu_count() or 1))             # more threads only add fork/join overhead on these op sizes
     dev = inp["imgs"].device
     full = dict(wt=wt, sc=inp["sc"], vol=vol, proj=inp["proj"], cam_pos=inp["cam_pos"], D=D, ro=inp["ro_host"], rd=inp["rd_host"],
@@ -362,23 +363,59 @@ def cpu_baseline_and_parity(wt, vol, inp, D, n_rays, budget_s=15.0):
     return cpu, par
 
 
-CURRENT_ROUND = 4
+CURRENT_ROUND = 5
+
+
+def this_host():
+    cpu = "?"
+    try:
+        cpu = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?")
+    except OSError:
+        pass
+    return {"cpu": cpu, "nproc": os.cpu_count()}
 
 
 def cpu_reference_file():
-    """The reference's OWN modules timed on CPU (tools/time_reference_cpu.py, build container only: the GPU box has no /root/reference): the newest
-    profiles/rNN_cpu_reference.json, attached only when it was generated in THIS round (the file carries round / commit / date / host / core count);
-    a stale file is refused with the reason instead of being re-attached to every line forever."""
+    """The reference's OWN modules timed on CPU (tools/time_reference_cpu.py; the GPU box has no /root/reference at bench time, so the number is a
+    provenance-stamped file).  Files of THIS round only (profiles/rNN_cpu_reference*.json carry round / commit / date / host / CPU model / core count; a
+    stale file is refused with the reason instead of being re-attached to every line forever).  Preferred: the file measured on a box with THIS box's CPU
+    model and core count (tools/reference_cpu_on_gpu_box.sh ships an untracked copy of the reference to a GPU box and times it on its host cores --
+    SURVEY 8(d)); otherwise the newest file, with `same_host_type: false`."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_cpu_reference.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r{CURRENT_ROUND:02d}_cpu_reference*.json")))
     if not files:
-        return {"refused": "no profiles/rNN_cpu_reference.json (run tools/time_reference_cpu.py in the build container)"}
-    d = json.load(open(files[-1]))
-    meta = d.get("_meta") or {}
-    rel = os.path.relpath(files[-1], ROOT)
-    if meta.get("round") != f"r{CURRENT_ROUND:02d}":
-        return {"refused": f"{rel} was measured in round {meta.get('round', 'unknown (no _meta stamp)')}, this is round r{CURRENT_ROUND:02d}: re-run tools/time_reference_cpu.py"}
-    return dict(d, source=rel)
+        old = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_cpu_reference*.json")))
+        why = f"newest is {os.path.relpath(old[-1], ROOT)}" if old else "none found"
+        return {"refused": f"no profiles/r{CURRENT_ROUND:02d}_cpu_reference*.json from this round ({why}): re-run tools/time_reference_cpu.py / tools/reference_cpu_on_gpu_box.sh"}
+    here = this_host()
+    cands = []
+    for f in files:
+        d = json.load(open(f))
+        meta = d.get("_meta") or {}
+        if meta.get("round") != f"r{CURRENT_ROUND:02d}":
+            continue
+        same = meta.get("cpu") == here["cpu"] and meta.get("nproc") == here["nproc"]
+        cands.append((same, f, d))
+    if not cands:
+        return {"refused": "the cpu_reference files of this round carry no matching _meta stamp"}
+    cands.sort(key=lambda c: (c[0], c[1]))
+    same, f, d = cands[-1]
+    return dict(d, source=os.path.relpath(f, ROOT), same_host_type=bool(same), this_host=here)
+
+
+def parity_reference_block(dev, precision):
+    """HIP vs the REFERENCE's own outputs at BASELINE scale (tests/golden/ref_c2_sample.npz = config 2, ref_c1.npz = config 1 exactly; generated by
+    tests/golden/make_golden_scale.py from the imported reference modules): volume build, sampler stage on the reference's inputs, render_core on the
+    reference's sample lists, render() end to end, extract_fields.  Test infrastructure on the checker side only (tests/refscale_util.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    out = {}
+    try:
+        import refscale_util as RU
+        for name in ("c2", "c1"):
+            out[name] = RU.report(name, dev, precision)
+    except FileNotFoundError as e:
+        out["refused"] = f"golden file missing: {e}"
+    return out
 
 
 def median_ms(fn, reps=5):
@@ -656,6 +693,7 @@ def main():
             vol0 = pipeline.build_volume(wt, inp["imgs"], inp["aff"], inp["origin"], a.vol, 2.0 / (a.vol - 1))     # the scene cpu_baseline's images belong to
             result["cpu_baseline"], result["parity_fullsize"] = cpu_baseline_and_parity(wt, vol0, inp, a.vol, a.cpu_rays)
             result["cpu_baseline_reference"] = cpu_reference_file()
+            result["parity_reference"] = parity_reference_block(dev, a.precision)
             vol0 = None
         if world == 1 and not a.quick:
             vol = outs = mesh = None

@@ -654,7 +654,6 @@ def ray_upsample(rays_o, rays_d, z, sdf, inv_s, maskvol, D, n_imp, streaming=Non
     return new_z, new_pts, lst[:int(cnt.item())]
 
 
-# ---------------------------------------------------------------------------------------------------------- marching cubes
 @_on_device
 def ray_finalize(rays_o, rays_d, z, sample_dist, maskvol, D):
     """Stage entry point of render_core's head (sparse_neus_renderer.py:204-231): z SAMPLE-MAJOR [S,R] -> dict(mid_z, dists, pm [S,R], pts [S,R,3],
@@ -670,6 +669,59 @@ def ray_finalize(rays_o, rays_d, z, sample_dist, maskvol, D):
     return o
 
 
+@_on_device
+def ray_composite(rays_o, rays_d, mid_z, dists, pm, sdf, grad, rgb, nviews, inv_s, alpha_inter_ratio=1.0, background=1.0):
+    """Stage entry point of render_core's tail (sparse_neus_renderer.py:340-455): NeuS opacities from (sdf, gradient, section length), transmittance,
+    weights, colour / depth / depth variance, the per-ray colour mask (> 8 samples seen by >= 2 views).  Per-sample inputs SAMPLE-MAJOR [S,R(,3)],
+    nviews uint8 [S,R].  -> dict(color [R,3], depth, weights_sum, weights_max, depth_var, alpha_sum [R], grad_err [R,2], color_mask uint8 [R],
+    weights / cdf [S,R])."""
+    S, R = mid_z.shape
+    dev = mid_z.device
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    o = dict(color=f(R, 3), depth=f(R), weights=f(S, R), cdf=f(S, R), weights_sum=f(R), weights_max=f(R), depth_var=f(R), alpha_sum=f(R),
+             grad_err=f(R, 2), color_mask=torch.empty(R, dtype=torch.uint8, device=dev))
+    check(_lib.lib().o2345_ray_composite(_p(rays_o), _p(rays_d), R, S, _p(mid_z), _p(dists), _p(pm), _p(sdf), _p(grad), _p(rgb), _p(nviews, torch.uint8),
+                                         float(inv_s), float(alpha_inter_ratio), float(background), _p(o["color"]), _p(o["depth"]), _p(o["weights"]),
+                                         _p(o["cdf"]), _p(o["weights_sum"]), _p(o["weights_max"]), _p(o["depth_var"]), _p(o["alpha_sum"]),
+                                         _p(o["grad_err"]), _p(o["color_mask"], torch.uint8), _stream()), "ray_composite")
+    return o
+
+
+@_on_device
+def render_core(scene, rays_o, rays_d, z, sample_dist, inv_s, alpha_inter_ratio=1.0, background=1.0, query_cam=None):
+    """The reference's render_core (sparse_neus_renderer.py:171-455) on GIVEN sample depths ``z`` SAMPLE-MAJOR [S,R] -- everything of a render() call that
+    lies downstream of the hierarchical sampler, composed from the public stage entries in the order o2345_render_rays runs them: o2345_ray_finalize
+    (mid points, section lengths, occupancy, defaults, occupied-point list; the "first 100 points" rule of :222-223 when no point is occupied) ->
+    SDF + analytic gradient on the listed points -> valid-view counts of the unlisted points -> Projector + GeneralRenderingNetwork on the listed points
+    -> o2345_ray_composite.  scene: the dict of render_rays.  -> dict: render_rays' per-sample / per-ray keys (+ ``list``)."""
+    S, R = z.shape
+    D = scene["vol_cl"].shape[0]
+    V, H, W, _ = scene["cmaps"].shape
+    o = ray_finalize(rays_o, rays_d, z, sample_dist, scene["maskvol"], D)
+    n = int(o["count"])                                        # (a stage composition on the host: one read-back; o2345_render_rays keeps the count on the device)
+    if n < 1:                                                  # :222-223 -- ray 0's samples 0..99 in the reference's ray-major order
+        n = min(100, S)
+        o["list"][:n] = torch.arange(n, dtype=torch.int32, device=z.device) * R
+    lst = o["list"][:n].contiguous()
+    pts = o["pts"].view(-1, 3)
+    sdf_precision = config.sdf_precision(scene.get("sdf_precision"))
+    res = {"sdf": o["sdf"].view(-1), "grad": o["grad"].view(-1, 3)}
+    sdf_mlp(scene["sdf_blob"], scene["vol_cl"], pts, variant=2, index=lst, out=res, precision=sdf_precision)
+    nviews = torch.zeros(S * R, dtype=torch.uint8, device=z.device)
+    check(_lib.lib().o2345_view_count_unlisted(_p(pts), S * R, _p(o["pm"]), _p(scene["maskvol"]), D, _p(scene["proj"]), V, H, W,
+                                               _p(nviews, torch.uint8), _stream()), "view_count_unlisted")
+    xb, mb = scene.get("color_x3_blob"), scene.get("color_mfma_blob")
+    use_x3 = xb is not None and config.color_precision(scene.get("color_precision")) == "f16x3"
+    L = _lib.lib()
+    fn = L.o2345_color_points_x3 if use_x3 else L.o2345_color_points_mfma
+    check(fn(_p(xb if use_x3 else mb), _p(scene["vol_cl"]), _p(scene["maskvol"]), D, _p(scene["cmaps"]), _p(scene["proj"]), _p(scene["cam_pos"]), V, H, W,
+             _p(pts), _p(lst, torch.int32), None, n, _p(query_cam), None, _p(o["rgb"]), _p(nviews, torch.uint8), None, _stream()), "color_points")
+    c = ray_composite(rays_o, rays_d, o["mid_z"], o["dists"], o["pm"], o["sdf"], o["grad"], o["rgb"], nviews.view(S, R), inv_s, alpha_inter_ratio, background)
+    c.update(mid_z=o["mid_z"], dists=o["dists"], pm=o["pm"], sdf=o["sdf"], grad=o["grad"], rgb=o["rgb"], nviews=nviews.view(S, R), list=lst, z_vals=z)
+    return c
+
+
+# ---------------------------------------------------------------------------------------------------------- marching cubes
 @_on_device
 def mesh_pack(verts_idx, tris, grid_R, bound_min=(-1.0, -1.0, -1.0), bound_max=(1.0, 1.0, 1.0), scale_mat=None, trans_mat=None, rgb=None):
     """Index-space vertices (fp64 [N,3]) + triangles -> (vertex records uint8 [N,16|12], face records uint8 [M,13]) of a binary PLY;

@@ -168,6 +168,34 @@ class SparseNeuSRenderer(nn.Module):
                 "blended_color_patch_mask": None, "weights_sum_fg": o["weights_sum"][:, None]}
 
     @torch.no_grad()
+    def render_core(self, rays_o, rays_d, z_vals, sample_dist, lod, sdf_network, rendering_network, background_alpha=None,
+                    background_sampled_color=None, background_rgb=None, alpha_inter_ratio=0.0, conditional_volume=None,
+                    conditional_valid_mask_volume=None, feature_maps=None, color_maps=None, w2cs=None, intrinsics=None, img_wh=None, query_c2w=None,
+                    if_general_rendering=True, if_render_with_grad=True, img_index=None, rays_uv=None, bg_num=0):
+        """render_core on GIVEN sample depths z_vals [N_rays, n_samples] (:171-455): the part of render() downstream of the hierarchical sampler, in the
+        reference's call form with the reference's returned keys.  Composed from the C ABI's stage entries (ops.render_core)."""
+        if not if_general_rendering or bg_num or self.if_fitted_rendering:
+            raise NotImplementedError("o2345 render_core: general rendering, bg_num = 0 (the released val / export configuration)")
+        cm, proj, cam_pos = _scene_maps(feature_maps, color_maps, w2cs, intrinsics)
+        scene = dict(sdf_blob=sdf_network.sdf_layer.blob(), vol_cl=channel_last(conditional_volume),
+                     maskvol=_attr_cache(conditional_valid_mask_volume, "_o2345_flat", (), lambda: conditional_valid_mask_volume.reshape(-1).contiguous().float()),
+                     cmaps=cm, proj=proj, cam_pos=cam_pos, color_mfma_blob=rendering_network.mfma_blob(), color_x3_blob=rendering_network.x3_blob())
+        var = self.variance_network.variance
+        inv_s = float(torch.exp(var.detach() * 10.0).clip(1e-6, 1e6))
+        o = ops.render_core(scene, rays_o.contiguous().float(), rays_d.contiguous().float(), z_vals.t().contiguous().float(), float(sample_dist), inv_s,
+                            float(alpha_inter_ratio), 0.0 if background_rgb is None else float(background_rgb),
+                            query_c2w.reshape(-1, 4, 4)[0, :3, 3].contiguous().float())
+        R, S = z_vals.shape
+        dev = rays_o.device
+        ge = o["grad_err"].double().sum(0)
+        return {"color": o["color"], "color_mask": o["color_mask"].view(torch.bool)[:, None], "color_mlp": None, "color_mlp_mask": None,
+                "sdf": o["sdf"].t().reshape(-1, 1), "depth": o["depth"][:, None], "dists": o["dists"].t(), "gradients": o["grad"].permute(1, 0, 2),
+                "variance": torch.full((R * S, 1), 1.0 / inv_s, device=dev), "mid_z_vals": o["mid_z"].t(), "weights": o["weights"].t(),
+                "weights_sum": o["weights_sum"][:, None], "alpha_sum": o["alpha_sum"][:, None], "alpha_mean": o["alpha_sum"].sum() / (R * S),
+                "cdf": o["cdf"].t(), "gradient_error": (ge[0] / (ge[1] + 1e-5)).float(), "inside_sphere": o["pm"].t(), "blended_color_patch": None,
+                "blended_color_patch_mask": None, "weights_sum_fg": o["weights_sum"][:, None]}
+
+    @torch.no_grad()
     def extract_fields(self, bound_min, bound_max, resolution, query_func, device, **kwargs):
         """u = -sdf on linspace(bound_min, bound_max, resolution)^3 (:881-905), as a DEVICE tensor [R,R,R].  The reference's own bounds (-1, 1): one fused
         launch, lattice generated in-kernel, layer 0 from per-axis tables.  Any other box: the three axes from torch.linspace on the host exactly as the

@@ -16,9 +16,10 @@ def env_rank_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
-def init(backend=None):
+def init(backend=None, force=False):
+    """Join the job's process group (a single process needs none; ``force`` = initialise it anyway, e.g. to exercise the RCCL path on one device)."""
     rank, world, local = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")

@@ -18,7 +18,8 @@ import torch.nn as nn
 
 from . import recon as O
 
-REF = "/root/reference/reconstruction"
+# the reference tree; O2345_REFERENCE_DIR points at an untracked working copy when the tree is shipped to the GPU box for CPU timing (tools/reference_cpu_on_gpu_box.sh)
+REF = os.environ.get("O2345_REFERENCE_DIR", "/root/reference/reconstruction")
 
 
 def available():

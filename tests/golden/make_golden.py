@@ -90,6 +90,48 @@ def main_perturb(seed=1234):
           float(np.abs(out["ren_color_fine"] - g0["ren_color_fine"]).max()))
 
 
+def main_perturb2(seed=4321):
+    """tests/golden/ref_perturb2.npz: TWO consecutive 512-ray render() calls under ONE torch.manual_seed -- the first two chunks of the trainer's loop
+    over the 40 x 40 query image (trainer_generic.py:503-524, perturb = 1.0 from the conf).  The reference draws from the HOST generator twice per call:
+    t_rand = torch.rand(z_vals.shape) (sparse_neus_renderer.py:506-515) and pts_random = torch.rand([1024, 3]) (:606), so the second chunk's jitter depends
+    on the first chunk having drawn both.  Stored: per call the sample lists handed to render_core, the per-ray results and sdf_random."""
+    torch.set_grad_enabled(False)
+    cfg = CFG
+    sc, fmaps, pts, _, _ = inputs()
+    HW = cfg["HW"]
+    sdfnet, rnet, var, renderer = networks(cfg)
+    T = torch.from_numpy
+    here = os.path.dirname(os.path.abspath(__file__))
+    g0 = np.load(os.path.join(here, "ref_small.npz"))
+    dense, mask = T(g0["dense"])[None], T(g0["mask"])[None, None]
+    ro, rd = pkg.synth.gen_rays(sc["query_intrinsic"], sc["query_c2w"], HW, HW)
+    near, far = T(sc["query_near_far"][:1]), T(sc["query_near_far"][1:])
+    seen_z = []
+    core = renderer.render_core
+    renderer.render_core = lambda ro_, rd_, z_, *a, **k: (seen_z.append(z_.clone()), core(ro_, rd_, z_, *a, **k))[1]
+    out = {"seed": np.int64(seed), "chk_rays": np.float64(rd.astype(np.float64).sum())}
+    torch.manual_seed(seed)
+    for c in range(2):
+        s = slice(512 * c, 512 * (c + 1))
+        ren = renderer.render(T(ro[s]), T(rd[s]), near, far, sdfnet, rnet, background_rgb=1.0, alpha_inter_ratio=1.0, lod=0,      # perturb_overwrite = -1
+                              conditional_volume=dense, conditional_valid_mask_volume=mask, feature_maps=T(fmaps), color_maps=T(sc["images"]),
+                              w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW], query_c2w=T(sc["query_c2w"])[None],
+                              if_render_with_grad=False)
+        for k in ("color_fine", "depth", "weights_sum", "sdf_random"):
+            out[f"c{c}_{k}"] = ren[k].numpy()
+        out[f"c{c}_z_vals"] = seen_z[-1].numpy()
+    # the host stream the two calls consumed, restated: the goldens above must be reproducible from it
+    torch.manual_seed(seed)
+    for c in range(2):
+        out[f"c{c}_t_rand"] = torch.rand(512, 64).numpy()
+        out[f"c{c}_pts_random"] = (torch.rand([1024, 3]).float() * 2 - 1).numpy()
+        chk = sdfnet.sdf(T(out[f"c{c}_pts_random"]), dense, lod=0)["sdf_pts_scale0"].numpy()
+        assert np.array_equal(chk, out[f"c{c}_sdf_random"]), "the restated host stream is not what render() drew"
+    path = os.path.join(here, "ref_perturb2.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; second-chunk colour max", float(out["c1_color_fine"].max()))
+
+
 TRAINED = ((0.62, 0.5, None), (0.45, 0.0, 1.0), (0.65, 1.0, None), (0.2, 0.5, None))     # (variance, alpha_inter_ratio, background_rgb)
 TRAINED_SDF_SHIFT = -0.3      # added to the SDF output bias (sdf_layer.lin2.bias[0]): moves the zero level set of the seeded field into the rays'
                               # valid range (min SDF over the valid samples of ref_small.npz is 0.117), so that sharp sigmoids have a surface to find
@@ -244,6 +286,8 @@ def main():
 if __name__ == "__main__":
     if "--perturb" in sys.argv:
         main_perturb()
+    elif "--perturb2" in sys.argv:
+        main_perturb2()
     elif "--featurenet" in sys.argv:
         main_featurenet()
     elif "--trained" in sys.argv:

@@ -1,0 +1,233 @@
+"""Reference-generated golden vectors AT BASELINE SCALE: the REFERENCE's own modules (imported from /root/reference on CPU,
+stubs per SURVEY Appendix E / oracle/ref_import.py) run the whole hot path -- FeatureNet -> fused pyramid -> get_conditional_volume -> render in the
+runner's 512-ray chunks -> extract_fields -- on the configurations BASELINE.json names.  Build container only (the GPU box has no /root/reference):
+
+    python tests/golden/make_golden_scale.py c1        # -> ref_c1.npz          BASELINE config 1, exactly: V = 8 ring, 64^3, 64 seeded rays, 64 + 64, perturb 0
+    python tests/golden/make_golden_scale.py c2        # -> ref_c2_sample.npz   BASELINE config 2: 128^3, 8 x 512-ray chunks (= 8 rows) of the 512^2 image
+    python tests/golden/make_golden_scale.py ref       # -> ref_refcfg_sample.npz   the reference configuration: V = 32, 96^3, 2 chunks of the 256^2 val image
+
+A file stores seeds, the networks' state dicts and OUTPUTS only: the images / cameras / rays are regenerated from the seeds by `inputs()` on the machine
+that runs the comparison (numpy Generator streams and the closed-form camera rig are platform-stable; checksums are stored and checked).  Nothing here is
+product code; the HIP path is compared with these files in tests/test_gpu_refscale.py and in bench.py's parity_fullsize block.
+"""
+import hashlib
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+pkg = importlib.import_module("one-2-3-45_amd")
+
+CHUNK = 512                      # the runner's ray batch (trainer_generic.py:503: rays_o.split(self.batch_size)), conf val batch_size 512
+CONFIGS = {
+    # rays: "c1" = 64 pixels randint(64, 192) seed 0 of the 256^2 query image; "rows" = whole rows of the query image (one row of the
+    # 512^2 image = one 512-ray chunk of the trainer's loop; two rows of the 256^2 image = one chunk)
+    "c1": dict(name="ref_c1.npz", V=8, D=64, image_seed=0, net_seed=11, rays="c1", ray_scale=1, grid=("full", 64), n_dense=20000,
+               variance=(0.2,)),
+    "c2": dict(name="ref_c2_sample.npz", V=8, D=128, image_seed=3, net_seed=12, rays="rows", ray_scale=2, rows=(40, 104, 168, 232, 296, 360, 424, 488),
+               grid=("block", 256, (96, 96, 96), 64), n_dense=100000, variance=(0.2, 0.5), trained_rows=(232, 296)),
+    "ref": dict(name="ref_refcfg_sample.npz", V=32, D=96, image_seed=5, net_seed=13, rays="rows", ray_scale=1, rows=(100, 101, 140, 141),
+                grid=("block", 256, (96, 96, 96), 64), n_dense=20000, variance=(0.2,)),
+}
+UPSAMPLE_TRACE_RAYS = 512        # the sampler's per-round inputs / outputs are kept for the first chunk only
+
+
+def inputs(cfg):
+    """Seeded inputs of one configuration: scene dict (pkg.synth.make_scene), rays [R,3] x 2 in chunk order, chunk size."""
+    sc = pkg.synth.make_scene(cfg["V"], image_seed=cfg["image_seed"])
+    ro, rd = pkg.synth.gen_rays(sc["query_intrinsic"], sc["query_c2w"], 256, 256, scale=cfg["ray_scale"])
+    W = 256 * cfg["ray_scale"]
+    if cfg["rays"] == "c1":
+        rng = np.random.default_rng(0)
+        ys, xs = rng.integers(64, 192, 64), rng.integers(64, 192, 64)
+        sel = ys * W + xs
+        chunk = 64
+    else:
+        sel = np.concatenate([np.arange(r * W, (r + 1) * W) for r in cfg["rows"]])
+        chunk = CHUNK
+    return sc, ro[sel].copy(), rd[sel].copy(), sel, chunk
+
+
+def checksums(sc, ro, rd):
+    f = lambda a: np.float64(np.asarray(a, np.float64).sum())
+    return {"chk_images": f(sc["images"]), "chk_aff": f(sc["affine_mats"]), "chk_rays_o": f(ro), "chk_rays_d": f(rd), "chk_w2cs": f(sc["w2cs"])}
+
+
+def grid_box(cfg):
+    """-> (bound_min [3], bound_max [3], resolution) of the extract_fields call of this configuration, or None."""
+    g = cfg["grid"]
+    if g is None:
+        return None
+    if g[0] == "full":
+        return torch.tensor([-1.0] * 3), torch.tensor([1.0] * 3), g[1]
+    _, R, origin, B = g
+    lin = torch.linspace(-1, 1, R)                                   # nodes of the R^3 extraction lattice: the block's corners are lattice nodes
+    o = torch.tensor(origin)
+    return lin[o], lin[o + B - 1], B
+
+
+def build_reference_networks(cfg):
+    """The reference's FeatureNet + lod-0 networks, seeded, with every zero-initialised path perturbed (make_golden.networks) and some negative ABN gammas."""
+    import make_golden as MG
+    from oracle import ref_import as RI
+    RI.load()
+    from models.featurenet import FeatureNet
+    sdfnet, rnet, var, renderer = MG.networks(dict(D=cfg["D"], seed=cfg["net_seed"]))
+    torch.manual_seed(cfg["net_seed"] + 100)
+    fnet = FeatureNet()
+    g = torch.Generator().manual_seed(cfg["net_seed"] + 100)
+    for m in fnet.modules():
+        if type(m).__name__ == "InPlaceABN":
+            m.weight.data = (1 + 0.2 * torch.randn(m.weight.shape, generator=g)) * torch.where(torch.rand(m.weight.shape, generator=g) < 0.2, -1.0, 1.0)
+            m.bias.data = 0.1 * torch.randn(m.bias.shape, generator=g)
+    return fnet, sdfnet, rnet, var, renderer
+
+
+def fused_pyramid(fnet, imgs):
+    """GenericTrainer.obtain_pyramid_feature_maps (trainer_generic.py:1104-1125) on the reference's FeatureNet."""
+    import torch.nn.functional as F
+    f2, s1, s0 = fnet(imgs)
+    return torch.cat([F.interpolate(f2, scale_factor=4, mode="bilinear", align_corners=True),
+                      F.interpolate(s1, scale_factor=2, mode="bilinear", align_corners=True), s0], dim=1)
+
+
+REN_KEYS = ("color_fine", "depth", "weights_sum", "depth_variance", "weights_max", "color_fine_mask")
+
+
+def render_chunks(renderer, sdfnet, rnet, sc, T, ro, rd, chunk, dense, mask, fmaps, HW, trace_first=False):
+    """The trainer's chunk loop (trainer_generic.py:503-524) on the given rays; per-ray outputs concatenated, the sample lists render() hands to
+    render_core (:559) recorded, optionally the sampler's per-round inputs / outputs of the first chunk."""
+    near, far = T(sc["query_near_far"][:1]), T(sc["query_near_far"][1:])
+    seen_z, trace = [], []
+    core, up = renderer.render_core, renderer.up_sample
+
+    def core_hook(ro_, rd_, z_, *a, **k):
+        seen_z.append(z_.clone())
+        return core(ro_, rd_, z_, *a, **k)
+
+    def up_hook(ro_, rd_, z_, sdf_, n_imp, inv_s, **k):
+        new_z = up(ro_, rd_, z_, sdf_, n_imp, inv_s, **k)
+        if trace_first and len(seen_z) == 0 and ro_.shape[0] <= UPSAMPLE_TRACE_RAYS:
+            trace.append(dict(z=z_.clone(), sdf=sdf_.reshape(z_.shape).clone(), inv_s=float(inv_s), new_z=new_z.clone()))
+        return new_z
+
+    renderer.render_core, renderer.up_sample = core_hook, up_hook
+    acc = {k: [] for k in REN_KEYS + ("weights", "sdf", "gradients", "inside_sphere")}
+    try:
+        for s in range(0, ro.shape[0], chunk):
+            r = renderer.render(T(ro[s:s + chunk]), T(rd[s:s + chunk]), near, far, sdfnet, rnet, perturb_overwrite=0, background_rgb=1.0,
+                                alpha_inter_ratio=1.0, lod=0, conditional_volume=dense, conditional_valid_mask_volume=mask, feature_maps=fmaps,
+                                color_maps=T(sc["images"]), w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW],
+                                query_c2w=T(sc["query_c2w"])[None], if_render_with_grad=False)
+            n = min(chunk, ro.shape[0] - s)
+            for k in acc:
+                v = r[k]
+                acc[k].append(v.reshape(n, -1) if k == "sdf" else v)
+            print(f"  chunk {s // chunk}: {time.time() - T0:.0f} s", flush=True)
+    finally:
+        renderer.render_core, renderer.up_sample = core, up
+    out = {k: torch.cat(v, 0).numpy() for k, v in acc.items()}
+    out["z_vals"] = torch.cat(seen_z, 0).numpy()
+    return out, trace
+
+
+T0 = time.time()
+
+
+@torch.no_grad()
+def main(which):
+    cfg = CONFIGS[which]
+    sc, ro, rd, sel, chunk = inputs(cfg)
+    V, D, HW = cfg["V"], cfg["D"], 256
+    T = torch.from_numpy
+    fnet, sdfnet, rnet, var, renderer = build_reference_networks(cfg)
+    out = {"ray_ids": sel.astype(np.int64), "chunk": np.int64(chunk)}
+    out.update(checksums(sc, ro, rd))
+    # ---- volume build from the IMAGES
+    fmaps = fused_pyramid(fnet, T(sc["images"]))
+    print(f"[{which}] fused pyramid {tuple(fmaps.shape)} {time.time() - T0:.0f} s", flush=True)
+    cv = sdfnet.get_conditional_volume(feature_maps=fmaps[None], partial_vol_origin=T(sc["partial_vol_origin"])[None],
+                                       proj_mats=T(sc["affine_mats"])[None], sizeH=HW, sizeW=HW, lod=0)
+    dense, mask = cv["dense_volume_scale0"], cv["valid_mask_volume_scale0"]
+    print(f"[{which}] volume: {int(mask.sum())} kept voxels of {D ** 3}, {time.time() - T0:.0f} s", flush=True)
+    feats16 = sdfnet.compress_layer(fmaps)
+    rng = np.random.default_rng(cfg["net_seed"])
+    mflat = mask.reshape(-1).numpy() > 0
+    out["kept_voxels"] = np.int64(mflat.sum())
+    out["mask_bits"] = np.packbits(mflat)
+    out["mask_sha256"] = np.frombuffer(hashlib.sha256(mflat.astype(np.uint8).tobytes()).digest(), np.uint8)
+    kept = np.nonzero(mflat)[0]
+    vi = np.sort(rng.choice(kept, cfg["n_dense"], replace=False))                 # a sample of the kept voxels: all 16 channels
+    out["dense_idx"], out["dense_val"] = vi.astype(np.int64), dense[0].reshape(16, -1)[:, vi].t().contiguous().numpy()
+    out["dense_absmax"] = np.float32(dense.abs().max())
+    out["dense_sum"] = np.float64(dense.double().sum())
+    pi = np.sort(rng.choice(V * HW * HW, 6000, replace=False))                   # pixels (view, y, x): all channels of the fused pyramid / compressed maps
+    out["pix_idx"] = pi.astype(np.int64)
+    out["fmaps_val"] = fmaps.permute(0, 2, 3, 1).reshape(-1, 56)[pi].numpy()
+    out["fmaps_absmax"] = np.float32(fmaps.abs().max())
+    out["feats16_val"] = feats16.permute(0, 2, 3, 1).reshape(-1, 16)[pi].numpy()
+    out["feats16_absmax"] = np.float32(feats16.abs().max())
+    # ---- render() in the runner's chunks
+    for vi_, variance in enumerate(cfg["variance"]):
+        var.variance.data = torch.tensor(float(variance))
+        if vi_ == 0:
+            r_ro, r_rd = ro, rd
+        else:                                    # a trained model's inv_s = exp(10 variance) on a subset of the chunks
+            W = 256 * cfg["ray_scale"]
+            keep = np.concatenate([np.nonzero((sel // W) == r)[0] for r in cfg["trained_rows"]])
+            out[f"v{vi_}_ray_pos"] = keep.astype(np.int64)
+            r_ro, r_rd = ro[keep], rd[keep]
+        ren, trace = render_chunks(renderer, sdfnet, rnet, sc, T, r_ro, r_rd, chunk, dense, mask, fmaps, HW, trace_first=(vi_ == 0))
+        out[f"v{vi_}_variance"] = np.float64(variance)
+        for k in REN_KEYS + ("z_vals",):
+            out[f"v{vi_}_{k}"] = ren[k]
+        out[f"v{vi_}_weights"] = ren["weights"][:2048]          # per-sample weights of the first four chunks
+        n_full = min(r_ro.shape[0], 512)         # per-sample fields of the first chunk (sdf / gradients / occupancy at the final samples)
+        out[f"v{vi_}_sdf"] = ren["sdf"][:n_full]
+        out[f"v{vi_}_gradients"] = ren["gradients"][:n_full]
+        out[f"v{vi_}_inside"] = ren["inside_sphere"][:n_full]
+        for i, t in enumerate(trace):
+            for k in ("z", "sdf", "new_z"):
+                out[f"v{vi_}_up{i}_{k}"] = t[k].numpy()
+            out[f"v{vi_}_up{i}_inv_s"] = np.float64(t["inv_s"])
+        print(f"[{which}] variance {variance}: {r_ro.shape[0]} rays, weights_sum max {float(ren['weights_sum'].max()):.4f}, "
+              f"rays with weight > 0.5: {int((ren['weights_sum'] > 0.5).sum())}, colour-valid rays {int(ren['color_fine_mask'].sum())}, "
+              f"{time.time() - T0:.0f} s", flush=True)
+    var.variance.data = torch.tensor(float(cfg["variance"][0]))
+    # ---- extract_fields
+    box = grid_box(cfg)
+    if box is not None:
+        bmin, bmax, R = box
+        u = renderer.extract_fields(bmin, bmax, R, lambda p, **kw: sdfnet.sdf(p, **kw), "cpu", conditional_volume=dense, lod=0)
+        out["u"] = u
+        out["u_bounds"] = np.stack([bmin.numpy(), bmax.numpy()])
+        ins = u > 0
+        print(f"[{which}] extract_fields {R}^3: {int(ins.sum())} inside nodes, sign changes along x {int((ins[1:] != ins[:-1]).sum())}, "
+              f"{time.time() - T0:.0f} s", flush=True)
+    # ---- state dicts (parameters only: the reference runs every normalisation layer on batch statistics)
+    for prefix, net in (("fnet.", fnet), ("sdf.", sdfnet), ("ren.", rnet), ("var.", var)):
+        for k, v in net.state_dict().items():
+            if "num_batches_tracked" in k or "running_" in k:
+                continue
+            out["w:" + prefix + k] = v.numpy()
+    out["w:var.variance"] = np.float32(cfg["variance"][0])
+    for k, v in cfg.items():
+        if isinstance(v, (int, float)):
+            out["cfg_" + k] = np.float64(v)
+    path = os.path.join(HERE, cfg["name"])
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} {os.path.getsize(path) // 1024} KiB in {time.time() - T0:.0f} s")
+
+
+if __name__ == "__main__":
+    torch.set_grad_enabled(False)
+    for w in (sys.argv[1:] or ["c1"]):
+        main(w)

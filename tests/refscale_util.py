@@ -1,0 +1,192 @@
+"""HIP path vs the REFERENCE's own outputs at BASELINE scale: the measurements (test infrastructure, shared by tests/test_gpu_refscale.py, which asserts
+on them, and bench.py's `parity_reference` block, which reports them).  The golden files come from tests/golden/make_golden_scale.py (the imported
+reference modules, build container); nothing here touches the oracle except the marching-cubes checker of `field`."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if os.path.join(HERE, "golden") not in sys.path:
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+
+pkg = importlib.import_module("one-2-3-45_amd")
+ops = importlib.import_module("one-2-3-45_amd.ops")
+pipeline = importlib.import_module("one-2-3-45_amd.pipeline")
+
+
+def relerr(a, b, scale=None):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max() / max(1.0, float(np.abs(b).max()) if scale is None else scale))
+
+
+def load(name, dev=None, precision=None):
+    """Golden file `name` ("c1" | "c2" | "ref") + its regenerated seeded inputs + the HIP volume built from the images with the file's weights."""
+    import make_golden_scale as MS
+    cfg = MS.CONFIGS[name]
+    g = np.load(os.path.join(HERE, "golden", cfg["name"]))
+    sc, ro, rd, sel, chunk = MS.inputs(cfg)
+    for k, v in MS.checksums(sc, ro, rd).items():          # the seeded inputs regenerate bit-identically on this machine
+        assert v == g[k], f"input {k} differs from the one the golden file was generated on"
+    assert np.array_equal(sel, g["ray_ids"]) and chunk == int(g["chunk"])
+    dev = dev or torch.device("cuda:0")
+    w = lambda p: {k[len("w:" + p):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w:" + p)}
+    wt = pipeline.SceneWeights.from_state_dicts(dev, w("sdf."), w("ren."), float(g["w:var.variance"]), featurenet_sd=w("fnet."),
+                                                sdf_precision=precision, color_precision=precision)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    D = cfg["D"]
+    vol = pipeline.build_volume(wt, T(sc["images"]), T(sc["affine_mats"]), sc["partial_vol_origin"], D, 2.0 / (D - 1))
+    proj, cam_pos = pipeline.camera_terms(T(sc["intrinsics"]), T(sc["w2cs"]))
+    scene = dict(sdf_blob=wt.sdf_blob, vol_cl=vol["vol_cl"], maskvol=vol["maskvol"], cmaps=vol["cmaps"], proj=proj, cam_pos=cam_pos,
+                 color_mfma_blob=wt.color_mblob, color_x3_blob=wt.color_xblob, sdf_precision=wt.sdf_precision, color_precision=wt.color_precision)
+    return dict(name=name, cfg=cfg, g=g, sc=sc, ro=ro, rd=rd, chunk=chunk, dev=dev, wt=wt, T=T, D=D, vol=vol, scene=scene, MS=MS,
+                near=float(sc["query_near_far"][0]), far=float(sc["query_near_far"][1]), qcam=T(sc["query_c2w"][:3, 3].copy()))
+
+
+def variants(G):
+    g = G["g"]
+    for vi in range(len(G["cfg"]["variance"])):
+        pos = g[f"v{vi}_ray_pos"] if f"v{vi}_ray_pos" in g.files else np.arange(G["ro"].shape[0])
+        yield vi, float(g[f"v{vi}_variance"]), pos
+
+
+def volume(G):
+    """get_conditional_volume from the IMAGES: every mask bit, samples of the fused pyramid / compressed maps / dense volume (max abs err / max |reference|)."""
+    g, vol = G["g"], G["vol"]
+    mask = (vol["maskvol"].view(-1) > 0).cpu().numpy()
+    pi = torch.from_numpy(g["pix_idx"]).to(G["dev"])
+    vi = torch.from_numpy(g["dense_idx"]).to(G["dev"])
+    return {"kept_voxels": int(mask.sum()), "kept_voxels_reference": int(g["kept_voxels"]),
+            "mask_bits_exact": bool(np.array_equal(np.packbits(mask), g["mask_bits"])) and int(vol["n_voxels"]) == int(g["kept_voxels"]),
+            "fused_pyramid": relerr(vol["cmaps"].view(-1, 64)[pi][:, 3:59], g["fmaps_val"], float(g["fmaps_absmax"])),
+            "compressed_maps": relerr(vol["feats_nhwc"].view(-1, 16)[pi], g["feats16_val"], float(g["feats16_absmax"])),
+            "dense_volume": relerr(vol["vol_cl"].view(-1, 16)[vi], g["dense_val"], float(g["dense_absmax"])), "dense_voxels_compared": int(vi.numel())}
+
+
+def sampler(G, bin_frac=5e-3, floor=5e-7):
+    """o2345_ray_upsample on the per-round (z, sdf) of the REFERENCE's first chunk vs the reference's new depths."""
+    g, dev = G["g"], G["dev"]
+    res = {"rounds": 0, "dz_max": 0.0, "dz_over_bin_max": 0.0, "excess_max": -1.0, "samples": 0}
+    i = 0
+    while f"v0_up{i}_new_z" in g.files:
+        z, sdf, new_z = (torch.from_numpy(g[f"v0_up{i}_{k}"]) for k in ("z", "sdf", "new_z"))
+        n = z.shape[0]
+        nz, _, _ = ops.ray_upsample(G["T"](G["ro"][:n]), G["T"](G["rd"][:n]), z.t().contiguous().to(dev), sdf.t().contiguous().to(dev),
+                                    float(g[f"v0_up{i}_inv_s"]), G["vol"]["maskvol"], G["D"], new_z.shape[1])
+        dz = (nz.t().cpu() - new_z).abs()
+        idx = (torch.searchsorted(z.contiguous(), new_z.contiguous(), right=True) - 1).clamp(0, z.shape[1] - 2)
+        width = z.gather(1, idx + 1) - z.gather(1, idx)
+        res["dz_max"] = max(res["dz_max"], float(dz.max()))
+        res["dz_over_bin_max"] = max(res["dz_over_bin_max"], float((dz / width.clamp(min=1e-9)).max()))
+        res["excess_max"] = max(res["excess_max"], float((dz - torch.maximum(bin_frac * width, torch.tensor(floor))).max()))
+        res["samples"] += int(dz.numel())
+        i += 1
+    res["rounds"] = i
+    return res
+
+
+def core(G):
+    """render_core on the REFERENCE's own sample lists (ops.render_core = the stage entries) vs the reference's results, chunk by chunk; one dict per variance."""
+    g, dev, T, chunk = G["g"], G["dev"], G["T"], G["chunk"]
+    sd = (G["far"] - G["near"]) / 64
+    out = []
+    for vi, variance, pos in variants(G):
+        inv_s = float(np.clip(np.exp(10.0 * variance), 1e-6, 1e6))
+        zr = torch.from_numpy(g[f"v{vi}_z_vals"])
+        acc = {}
+        for s in range(0, len(pos), chunk):
+            p = pos[s:s + chunk]
+            o = ops.render_core(G["scene"], T(G["ro"][p]), T(G["rd"][p]), zr[s:s + chunk].t().contiguous().to(dev), sd, inv_s, 1.0, 1.0, G["qcam"])
+            for k in ("color", "depth", "weights_sum", "weights_max", "depth_var", "color_mask"):
+                acc.setdefault(k, []).append(o[k].cpu())
+            for k in ("weights", "sdf", "pm"):
+                acc.setdefault(k, []).append(o[k].t().cpu())
+            acc.setdefault("grad", []).append(o["grad"].permute(1, 0, 2).cpu())
+        o = {k: torch.cat(v, 0) for k, v in acc.items()}
+        e = dict(variance=variance, inv_s=inv_s, rays=int(len(pos)),
+                 color=relerr(o["color"], g[f"v{vi}_color_fine"]), depth=relerr(o["depth"][:, None], g[f"v{vi}_depth"]),
+                 weights_sum=relerr(o["weights_sum"][:, None], g[f"v{vi}_weights_sum"]), weights_max=relerr(o["weights_max"][:, None], g[f"v{vi}_weights_max"]),
+                 depth_var=relerr(o["depth_var"][:, None], g[f"v{vi}_depth_variance"]))
+        nw = g[f"v{vi}_weights"].shape[0]
+        e["weights"] = relerr(o["weights"][:nw], g[f"v{vi}_weights"])
+        nf = g[f"v{vi}_sdf"].shape[0]
+        inside = torch.from_numpy(g[f"v{vi}_inside"])
+        occ = inside > 0                           # the reference's defaults elsewhere: sdf = 100, gradient = 0 (:231) -- exactly
+        sref, gref = torch.from_numpy(g[f"v{vi}_sdf"]), torch.from_numpy(g[f"v{vi}_gradients"])
+        e["occupancy_exact"] = bool(torch.equal(o["pm"][:nf], inside))
+        e["defaults_exact"] = bool((o["sdf"][:nf][~occ] == 100).all()) and bool((sref[~occ] == 100).all()) and float(o["grad"][:nf][~occ].abs().sum()) == 0
+        e["sdf"] = relerr(o["sdf"][:nf][occ], sref[occ].numpy())
+        e["grad"] = relerr(o["grad"][:nf][occ], gref[occ].numpy())
+        e["color_mask_mismatches"] = int((o["color_mask"].bool()[:, None] != torch.from_numpy(g[f"v{vi}_color_fine_mask"])).sum())
+        out.append(e)
+    return out
+
+
+def end_to_end(G):
+    """render() per chunk exactly as the trainer's loop calls it vs the reference's images; one dict per variance."""
+    g, T, chunk, wt = G["g"], G["T"], G["chunk"], G["wt"]
+    out = []
+    v0 = (wt.variance, wt.inv_s)
+    try:
+        for vi, variance, pos in variants(G):
+            wt.variance, wt.inv_s = variance, float(np.clip(np.exp(10.0 * variance), 1e-6, 1e6))
+            outs = []
+            for s in range(0, len(pos), chunk):
+                p = pos[s:s + chunk]
+                o = pipeline.render(wt, G["vol"], G["scene"]["proj"], G["scene"]["cam_pos"], T(G["ro"][p]), T(G["rd"][p]), G["near"], G["far"], G["qcam"], want_z=True)
+                outs.append(dict({k: o[k].cpu() for k in ("color", "depth", "weights_sum", "color_mask")}, z=o["z_vals"].t().cpu()))
+            o = {k: torch.cat([x[k] for x in outs], 0) for k in outs[0]}
+            zerr = (o["z"] - torch.from_numpy(g[f"v{vi}_z_vals"])).abs().max(1).values
+            cerr = (o["color"] - torch.from_numpy(g[f"v{vi}_color_fine"])).abs().max(1).values
+            derr = (o["depth"][:, None] - torch.from_numpy(g[f"v{vi}_depth"])).abs()[:, 0]
+            same = zerr < 1e-6
+            q = lambda t, x: float(torch.quantile(t, x))
+            out.append({"variance": variance, "inv_s": wt.inv_s, "rays": int(len(pos)), "coarse_spacing": (G["far"] - G["near"]) / 63,
+                        "color_err_q50_q90_q99_max": [q(cerr, 0.5), q(cerr, 0.9), q(cerr, 0.99), float(cerr.max())],
+                        "depth_err_q50_q90_q99_max": [q(derr, 0.5), q(derr, 0.9), q(derr, 0.99), float(derr.max())],
+                        "frac_rays_color_gt_1e-4": float((cerr > 1e-4).float().mean()), "frac_rays_color_gt_1e-3": float((cerr > 1e-3).float().mean()),
+                        "z_err_max": float(zerr.max()), "rays_with_coinciding_lists": int(same.sum()),
+                        "color_err_max_on_coinciding_lists": float(cerr[same].max()) if same.any() else 0.0,
+                        "color_mask_mismatches": int((o["color_mask"].bool()[:, None] != torch.from_numpy(g[f"v{vi}_color_fine_mask"])).sum())})
+    finally:
+        wt.variance, wt.inv_s = v0
+    return out
+
+
+def field(G):
+    """extract_fields vs the reference's u (config 1: the whole 64^3 lattice through the fused lattice kernel; otherwise the central 64^3 block of the 256^3
+    lattice, points built like :887-889)."""
+    g, dev, wt = G["g"], G["dev"], G["wt"]
+    bmin, bmax, R = G["MS"].grid_box(G["cfg"])
+    uref = torch.from_numpy(g["u"])
+    assert np.array_equal(np.stack([bmin.numpy(), bmax.numpy()]), g["u_bounds"])
+    if G["cfg"]["grid"][0] == "full":
+        u = ops.sdf_mlp(wt.sdf_blob, G["vol"]["vol_cl"], None, variant=0, grid_R=R, sign=-1.0, precision=wt.sdf_precision, grid_tables=wt.grid_tables(R))["sdf"].view(R, R, R)
+    else:
+        ax = [torch.linspace(float(bmin[d]), float(bmax[d]), R) for d in range(3)]                         # :887-889
+        pts = torch.stack(torch.meshgrid(*ax, indexing="ij"), -1).reshape(-1, 3).contiguous().to(dev)
+        u = ops.sdf_mlp(wt.sdf_blob, G["vol"]["vol_cl"], pts, variant=0, sign=-1.0, precision=wt.sdf_precision)["sdf"].view(R, R, R)
+    u = u.cpu()
+    flips = (u > 0) != (uref > 0)
+    nflip = int(flips.sum())
+    res = {"grid": R, "field_err_max": float((u - uref).abs().max()), "field_scale": float(uref.abs().max()), "inside_nodes_reference": int((uref > 0).sum()),
+           "sign_flips": nflip, "abs_u_reference_at_flips_max": float(uref[flips].abs().max()) if nflip else 0.0}
+    if nflip == 0:
+        from oracle import mc as omc                       # the checker's marching cubes on the REFERENCE's field
+        v, t = ops.marching_cubes(u.to(dev).contiguous(), 0.0)
+        v_ref, t_ref = omc.marching_cubes(uref.numpy(), 0.0)
+        res["triangles"] = int(t.shape[0])
+        res["triangles_identical"] = bool(np.array_equal(t.cpu().numpy(), t_ref))
+        res["vertex_shift_max_cells"] = float(np.abs(v.cpu().numpy() - v_ref).max()) if v.shape[0] == v_ref.shape[0] else None
+    return res
+
+
+def report(name, dev=None, precision=None):
+    """Everything above for one golden file as one JSON-able dict (bench.py's `parity_reference` block)."""
+    G = load(name, dev, precision)
+    return {"golden": G["cfg"]["name"], "generator": "tests/golden/make_golden_scale.py (the imported reference modules, CPU)", "volume": volume(G),
+            "sampler_on_reference_inputs": sampler(G), "render_core_on_reference_lists": core(G), "render_end_to_end": end_to_end(G), "extract_fields": field(G)}

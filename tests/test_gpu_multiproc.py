@@ -85,3 +85,73 @@ def test_two_ranks_render_one_image_split_by_rays():
     assert all(all(r[3].values()) for r in res), res                         # colour, depth, weights_sum, colour mask of every ray
     assert res[0][4] > 0.5                                                   # the image shows a surface
     assert res[0][5] == res[1][5]                                            # both ranks built the same volume
+
+
+def test_eight_ranks_on_the_one_gpu_functional():
+    """the shape the driver's 8-GPU run has -- `bench.py --gpus 8` bare, re-executed under torch.distributed.run, eight ranks, rendezvous on
+    127.0.0.1, scene deal 0..7 per step, BASELINE config 3's 32 scenes dealt 4 per rank, a per-rank report with eight entries -- with all eight ranks
+    sharing the box's single device (gloo for the clock).  FUNCTIONAL ONLY: the printed rate is eight processes time-slicing one GPU, not a scaling number
+    (the line says so: shared_gpu_functional_run)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "4"                         # eight ranks on one host: no thread oversubscription
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-gpu", "--steps", "1", "--warmup", "1",
+                        "--no-cpu", "--vol", "64", "--ray-scale", "1", "--mesh-res", "64"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["shared_gpu_functional_run"] is True and d["steps"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "scenes x8" and d["rccl_ranks"] == 8 and d["backend"] == "gloo"
+    assert len(d["per_rank"]) == 8 and sorted(p["rank"] for p in d["per_rank"]) == list(range(8))
+    assert all(p["ms_per_step_own_clock"] > 0 for p in d["per_rank"])
+    assert abs(d["value"] - 8 * 65536 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    c3 = d["c3"]
+    assert c3["scenes"] == 32 and "4 per GPU on 8 GPU(s)" in c3["workload"] and len(c3["per_rank"]) == 8
+    assert all(p["scenes"] == 4 for p in c3["per_rank"])
+
+
+def _nccl_worker(q):
+    import importlib
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sh = importlib.import_module("one-2-3-45_amd.sharding")
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1")
+    rank, world, local = sh.init("nccl", force=True)               # the device_id= branch of sharding.init: RCCL communicator bound to cuda:0
+    dev = torch.device("cuda", local)
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    dist.barrier(device_ids=[local])
+    t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # the clock reduction of bench.py (sharding.max_over_ranks), on the device
+    b = torch.arange(1024, dtype=torch.float32, device=dev)
+    dist.broadcast(b, src=0)                                      # the optional weight broadcast's collective
+    out = [torch.empty_like(b)]
+    dist.all_gather(out, b)                                       # the intra-scene mode's result collective
+    torch.cuda.synchronize(dev)
+    q.put((float(t.item()), float(out[0].sum().item()), sh._reduce_device(dev) == dev))
+    sh.shutdown()
+
+
+def test_one_rank_rccl_init_barrier_and_collectives():
+    """The `nccl` (= RCCL) branch of sharding.init -- init_process_group(device_id=cuda:local) -- and the three collectives the package ever issues
+    (all_reduce for the clock, broadcast for the optional shared weights, all_gather for the intra-scene mode) executed once on RCCL: a one-rank communicator
+    is all a one-GPU box can host (RCCL refuses two ranks on one device); it proves the code path loads, binds the device and runs."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_PORT"] = str(port)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(q,))
+    p.start()
+    import queue
+    try:
+        res = q.get(timeout=300)
+    except queue.Empty:
+        res = None
+    p.join(30)
+    if p.is_alive():
+        p.kill()
+    assert res is not None and p.exitcode == 0, p.exitcode
+    assert res[0] == 3.5 and res[1] == float(sum(range(1024))) and res[2] is True

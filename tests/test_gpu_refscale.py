@@ -1,0 +1,96 @@
+"""GPU: the HIP path against the REFERENCE ITSELF at BASELINE scale -- no oracle in between.
+
+tests/golden/ref_c1.npz (BASELINE config 1, exactly), ref_c2_sample.npz (config 2: 128^3, eight 512-ray chunks of the 512^2 image, + two chunks with a
+trained model's variance) and ref_refcfg_sample.npz (the reference configuration: 32 views, 96^3) hold what the reference's own modules computed from the
+seeded images (tests/golden/make_golden_scale.py, run in the build container): FeatureNet -> fused pyramid -> get_conditional_volume -> render() in the
+runner's chunks -> extract_fields.  Here the same seeds go through the C ABI and every stage is compared with the file directly (tests/refscale_util.py):
+
+  volume      kept-voxel set bit-exact (all D^3 mask bits), fused pyramid / compressed maps / dense volume samples within a relative tolerance
+  sampler     o2345_ray_upsample on the reference's own per-round (z, sdf)              -> the reference's 16 new depths per ray and round
+  downstream  render_core on the reference's own sample lists (stage entries, ops.render_core) -> the reference's colour / depth / weights / masks
+  end to end  render() per chunk -> the reference's images: sample lists within one coarse section, hard caps on the error distribution
+  field       extract_fields -> the reference's u: same sign pattern => the same triangles
+"""
+import json
+import sys
+
+import pytest
+
+import refscale_util as RU
+
+pytestmark = pytest.mark.gpu
+
+# ---- the stated tolerances, HIP vs reference at these sizes (max abs error / max(1, max |reference|) unless noted; measured values: DESIGN.md section 4)
+TOL = dict(fmaps=2e-5, feats16=2e-5, dense=2e-4,
+           sampler_abs=2e-4, sampler_bin=5e-3, sampler_floor=5e-7,
+           core_color=1e-4, core_depth=5e-5, core_weights=5e-5, core_sdf=5e-5, core_grad=2e-4,
+           e2e_color_max=6e-2, e2e_color_q99=8e-3, e2e_frac_gt_1e3=0.06, u=2e-5)
+
+
+def show(G, what, res):
+    print(f"[refscale {G['name']}] {what}: {json.dumps(res)}", file=sys.stderr)
+
+
+@pytest.fixture(scope="module", params=["c1", "c2", "ref"])
+def G(request):
+    return RU.load(request.param)
+
+
+def test_volume_build_vs_reference(G):
+    """get_conditional_volume from the IMAGES (sparse_sdf_network.py:286-400 after FeatureNet + obtain_pyramid_feature_maps): every mask bit, samples of the
+    fused pyramid, of the compressed maps and of the dense latent volume."""
+    r = RU.volume(G)
+    show(G, "volume vs REFERENCE", r)
+    assert r["mask_bits_exact"] and r["kept_voxels"] == r["kept_voxels_reference"], "kept-voxel set differs from the reference's valid_mask_volume"
+    assert r["fused_pyramid"] < TOL["fmaps"] and r["compressed_maps"] < TOL["feats16"] and r["dense_volume"] < TOL["dense"], r
+
+
+def test_sampler_stage_on_the_references_own_inputs(G):
+    """up_sample + sample_pdf (sparse_neus_renderer.py:73-115, render_utils.py:8-51): o2345_ray_upsample driven with the per-round (z, sdf) the REFERENCE's
+    render() had in its first chunk -> the reference's new depths: within 2e-4 absolute and within max(5e-3 of the bin, 5e-7)."""
+    r = RU.sampler(G, TOL["sampler_bin"], TOL["sampler_floor"])
+    show(G, "sampler on the reference's inputs", r)
+    assert r["rounds"] == 4 and r["dz_max"] < TOL["sampler_abs"] and r["excess_max"] <= 0, r
+
+
+def test_render_core_on_the_references_own_sample_lists(G):
+    """Everything downstream of the sampler (render_core, :171-455: SDF + gradient, Projector + GeneralRenderingNetwork, NeuS compositing) evaluated by the HIP
+    stage entries ON THE REFERENCE'S sample lists -> the reference's per-ray and per-sample results, chunk by chunk."""
+    for e in RU.core(G):
+        show(G, "render_core on the reference's lists", e)
+        # a trained model's inv_s multiplies every SDF difference inside the sigmoid: the bound scales with it
+        amp = max(1.0, e["inv_s"] / 20.0)
+        assert e["color_mask_mismatches"] == 0 and e["occupancy_exact"] and e["defaults_exact"], e
+        assert e["sdf"] < TOL["core_sdf"] and e["grad"] < TOL["core_grad"], e
+        assert e["color"] < TOL["core_color"] * amp and e["depth"] < TOL["core_depth"] * amp, e
+        assert max(e["weights"], e["weights_sum"], e["weights_max"], e["depth_var"]) < TOL["core_weights"] * amp, e
+
+
+def test_render_end_to_end_vs_reference(G):
+    """render() (sparse_neus_renderer.py:457-635) per chunk, exactly as the trainer's loop calls it -> the reference's images.  The hierarchical sampler
+    amplifies fp32-class SDF differences (two runs of the reference on different hardware do not agree to 1e-5 either), so: every sample list within one
+    coarse section of the reference's, every ray whose list coincides agrees as tightly as the downstream test, and HARD CAPS on the distribution of the
+    colour error -- derived from THIS comparison (HIP vs reference), not from the oracle."""
+    for e in RU.end_to_end(G):
+        show(G, "render() end to end vs REFERENCE", e)
+        assert e["color_mask_mismatches"] == 0, e
+        assert e["z_err_max"] <= 1.001 * e["coarse_spacing"], e
+        amp = max(1.0, e["inv_s"] / 20.0)
+        assert e["color_err_max_on_coinciding_lists"] <= TOL["core_color"] * amp, e
+        if e["variance"] <= 0.3:                 # the regime the benchmark runs in; a trained inv_s sharpens every list difference into an O(1) colour difference
+            q50, q90, q99, mx = e["color_err_q50_q90_q99_max"]
+            assert mx <= TOL["e2e_color_max"], e
+            if e["rays"] >= 1000:
+                assert q99 <= TOL["e2e_color_q99"] and e["frac_rays_color_gt_1e-3"] <= TOL["e2e_frac_gt_1e3"], e
+
+
+def test_extract_fields_vs_reference(G):
+    """extract_fields (sparse_neus_renderer.py:881-905): u = -sdf on the reference's lattice.  Config 1: the whole 64^3 lattice through the fused lattice
+    kernel; config 2 / reference configuration: the central 64^3 block of the 256^3 lattice.  The same sign at every node => marching cubes (exact for an
+    identical sign pattern) yields the reference's triangles."""
+    r = RU.field(G)
+    show(G, "extract_fields vs REFERENCE", r)
+    assert r["field_err_max"] < TOL["u"] * max(1.0, r["field_scale"]), r
+    assert r["sign_flips"] <= 2 and r["abs_u_reference_at_flips_max"] <= r["field_err_max"], "a lattice node may change sign only inside the field's own error band"
+    if r["sign_flips"] == 0:
+        assert r["triangles_identical"] and r["vertex_shift_max_cells"] < 0.02, r

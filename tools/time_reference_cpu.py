@@ -1,9 +1,11 @@
 """Times the REFERENCE's own modules (imported from /root/reference, CPU, stubs per oracle/ref_import.py) on BASELINE config-2 inputs:
-SparseNeuSRenderer.render (512-ray chunks, like the runner) and extract_fields.  Build container only (the GPU box has no
-/root/reference); writes profiles/rNN_cpu_reference.json (NN = the current round, tools/profile_round.sh's tag) stamped with the commit, date, host and
-core count it was measured on; bench.py attaches the NEWEST such file as `cpu_baseline_reference` and refuses one from an older round.
+SparseNeuSRenderer.render (512-ray chunks, like the runner) and extract_fields.  Needs the reference tree: /root/reference in the build container, or
+O2345_REFERENCE_DIR = an untracked working copy shipped to the GPU box (tools/reference_cpu_on_gpu_box.sh -- SURVEY 8(d): "the reference's CPU path timed
+on the host cores of the same box").  Writes <out dir>/rNN_cpu_reference[_gpubox].json stamped with the commit, date, host, CPU model and core count it
+was measured on; bench.py attaches the file whose CPU model and core count are those of the box it runs on (else the newest, with the mismatch stated)
+and refuses files of an older round.
 
-    python tools/time_reference_cpu.py [seconds] [round tag, default r04]"""
+    python tools/time_reference_cpu.py [seconds] [round tag, default r05] [out dir, default profiles] [file suffix, default ""]"""
 import importlib
 import json
 import os
@@ -24,7 +26,10 @@ pkg = importlib.import_module("one-2-3-45_amd")
 @torch.no_grad()
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
-    tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
+    tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
+    out_dir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")
+    suffix = sys.argv[4] if len(sys.argv) > 4 else ""
+    torch.set_num_threads(min(32, os.cpu_count() or 1))            # the same cap as bench.py's oracle leg: more threads only add fork / join overhead on these op sizes
     V, HW, D = 8, 256, 128
     sc = pkg.synth.make_scene(V, image_seed=0)
     sdfnet, rnet, var, renderer = RI.build_networks(D, seed=0)
@@ -56,7 +61,7 @@ def main():
                             conditional_volume=dense, lod=0)
     de = time.time() - t1
     out = {"what": "the reference's own SparseNeuSRenderer.render / extract_fields (models/sparse_neus_renderer.py:457-635, 881-905) on CPU, "
-                   "BASELINE config-2 inputs (8 views 256^2, 128^3 volume), measured in the BUILD CONTAINER (not on the GPU box)",
+                   "BASELINE config-2 inputs (8 views 256^2, 128^3 volume); where it was measured: _meta.host / _meta.cpu / cores",
            "value": done / dt, "unit": "rays/s", "cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "kind": "reference",
            "sample": f"{done} rays in 512-ray chunks (the runner's batch size), {dt:.1f} s",
            "extract_fields_points_per_s": R ** 3 / de, "extract_fields_sample": f"{R}^3 grid, {de:.1f} s (a 256^3 grid is 64x that)"}
@@ -68,7 +73,10 @@ def main():
                     "date_utc": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ"), "host": platform.node(), "nproc": os.cpu_count(),
                     "cpu": next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?"), "torch": torch.__version__,
                     "script": "tools/time_reference_cpu.py"}
-    path = os.path.join(ROOT, "profiles", f"{tag}_cpu_reference.json")
+    out["_meta"]["reference_dir"] = RI.REF
+    out["_meta"]["has_gpu"] = bool(torch.cuda.is_available())
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, f"{tag}_cpu_reference{suffix}.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out))
 
