@@ -64,7 +64,9 @@ def volume(G):
             "mask_bits_exact": bool(np.array_equal(np.packbits(mask), g["mask_bits"])) and int(vol["n_voxels"]) == int(g["kept_voxels"]),
             "fused_pyramid": relerr(vol["cmaps"].view(-1, 64)[pi][:, 3:59], g["fmaps_val"], float(g["fmaps_absmax"])),
             "compressed_maps": relerr(vol["feats_nhwc"].view(-1, 16)[pi], g["feats16_val"], float(g["feats16_absmax"])),
-            "dense_volume": relerr(vol["vol_cl"].view(-1, 16)[vi], g["dense_val"], float(g["dense_absmax"])), "dense_voxels_compared": int(vi.numel())}
+            "dense_volume": relerr(vol["vol_cl"].view(-1, 16)[vi], g["dense_val"], float(g["dense_absmax"])),
+            "dense_volume_rms": float((vol["vol_cl"].view(-1, 16)[vi].cpu().double() - torch.from_numpy(g["dense_val"]).double()).pow(2).mean().sqrt() / float(g["dense_absmax"])),
+            "dense_voxels_compared": int(vi.numel())}
 
 
 def sampler(G, bin_frac=5e-3, floor=5e-7):
@@ -145,7 +147,13 @@ def end_to_end(G):
             derr = (o["depth"][:, None] - torch.from_numpy(g[f"v{vi}_depth"])).abs()[:, 0]
             same = zerr < 1e-6
             q = lambda t, x: float(torch.quantile(t, x))
+            own = None
+            if vi == 0 and "selfsens0_color_err" in g.files:      # the REFERENCE against itself on a volume that differs by fp32-class noise (make_golden_scale.SELFSENS_*)
+                sc_, sz_ = torch.from_numpy(g["selfsens0_color_err"]).reshape(-1), torch.from_numpy(g["selfsens0_z_err"])
+                own = {"volume_noise_sigma_over_absmax": float(g["selfsens0_sigma"]), "color_err_q50_q90_q99_max": [q(sc_, 0.5), q(sc_, 0.9), q(sc_, 0.99), float(sc_.max())],
+                       "frac_rays_color_gt_1e-3": float((sc_ > 1e-3).float().mean()), "z_err_max": float(sz_.max())}
             out.append({"variance": variance, "inv_s": wt.inv_s, "rays": int(len(pos)), "coarse_spacing": (G["far"] - G["near"]) / 63,
+                        "reference_vs_itself_on_a_noisy_volume": own,
                         "color_err_q50_q90_q99_max": [q(cerr, 0.5), q(cerr, 0.9), q(cerr, 0.99), float(cerr.max())],
                         "depth_err_q50_q90_q99_max": [q(derr, 0.5), q(derr, 0.9), q(derr, 0.99), float(derr.max())],
                         "frac_rays_color_gt_1e-4": float((cerr > 1e-4).float().mean()), "frac_rays_color_gt_1e-3": float((cerr > 1e-3).float().mean()),

@@ -423,11 +423,13 @@ def test_mirror_caches_follow_in_place_updates(S):
             var.copy_(old)
 
 
-def test_chunked_mirror_render_equals_one_call(S):
+def test_chunked_mirror_render_equals_one_call(S, monkeypatch):
     """The trainer's val loop (trainer_generic.py:365, 415-416, 506-524): SparseNeuSRenderer.render per 512-ray chunk of an image == ONE render call on the
     whole image, bit for bit (every chunk of this image has occupied samples, so the reference's per-call quirks cannot fire), in the deterministic mode
-    and -- with the chunks' jitter drawn from the same host generator state -- in the default perturb = 1 mode."""
+    and -- with the whole-image call given the jitter the chunks draw: per chunk torch.rand(R, 64) THEN torch.rand([1024, 3]) on the host generator, the
+    reference's interleaving (sparse_neus_renderer.py:506-515, 606) -- in the default perturb = 1 mode."""
     import importlib
+    ops = importlib.import_module("one-2-3-45_amd.ops")
     g, G, T = S["G"]["g"], S["G"], S["T"]
     sc, HW = G["sc"], G["cfg"]["HW"]
     synth = importlib.import_module("one-2-3-45_amd.synth")
@@ -441,8 +443,17 @@ def test_chunked_mirror_render_equals_one_call(S):
     keys = ("color_fine", "depth", "weights", "weights_sum", "depth_variance", "gradients", "inside_sphere", "color_fine_mask", "cdf_fine")
     for perturb in (0, -1):                                       # -1: the renderer's own perturb = 1.0
         torch.manual_seed(5)
+        if perturb < 0:                                           # the host stream of the chunk loop, restated: t_rand, pts_random, t_rand, pts_random, ...
+            draws = []
+            for a in ro.split(512):
+                draws.append(torch.rand(a.shape[0], 64))
+                torch.rand([1024, 3])
+            tr = torch.cat(draws).to(ro.device)
+            real = ops.render_rays
+            monkeypatch.setattr(ops, "render_rays", lambda *a_, **k_: real(*a_, **dict(k_, t_rand=tr)))
         whole = S["ren"].render(ro, rd, near, far, S["sdf"], S["rnet"], perturb_overwrite=perturb, **kw)
-        torch.manual_seed(5)                                      # torch.rand(R, 64) per chunk continues the stream the single call draws at once
+        monkeypatch.undo()
+        torch.manual_seed(5)
         parts = [S["ren"].render(a, b, near, far, S["sdf"], S["rnet"], perturb_overwrite=perturb, **kw) for a, b in zip(ro.split(512), rd.split(512))]
         assert all(int((p["inside_sphere"] > 0).sum()) > 512 for p in parts)
         for k in keys:

@@ -21,10 +21,10 @@ import refscale_util as RU
 pytestmark = pytest.mark.gpu
 
 # ---- the stated tolerances, HIP vs reference at these sizes (max abs error / max(1, max |reference|) unless noted; measured values: DESIGN.md section 4)
-TOL = dict(fmaps=2e-5, feats16=2e-5, dense=2e-4,
+TOL = dict(fmaps=2e-5, feats16=2e-5, dense=5e-5, dense_rms=3e-6,
            sampler_abs=2e-4, sampler_bin=5e-3, sampler_floor=5e-7,
            core_color=1e-4, core_depth=5e-5, core_weights=5e-5, core_sdf=5e-5, core_grad=2e-4,
-           e2e_color_max=6e-2, e2e_color_q99=8e-3, e2e_frac_gt_1e3=0.06, u=2e-5)
+           e2e_vs_own_quantiles=3.0, e2e_vs_own_max=2.0, u=5e-5)
 
 
 def show(G, what, res):
@@ -43,6 +43,8 @@ def test_volume_build_vs_reference(G):
     show(G, "volume vs REFERENCE", r)
     assert r["mask_bits_exact"] and r["kept_voxels"] == r["kept_voxels_reference"], "kept-voxel set differs from the reference's valid_mask_volume"
     assert r["fused_pyramid"] < TOL["fmaps"] and r["compressed_maps"] < TOL["feats16"] and r["dense_volume"] < TOL["dense"], r
+    # the volume differs from the reference's by no more than the noise the reference's own end-to-end sensitivity was measured with (3e-6 rms)
+    assert r["dense_volume_rms"] <= TOL["dense_rms"], r
 
 
 def test_sampler_stage_on_the_references_own_inputs(G):
@@ -67,21 +69,24 @@ def test_render_core_on_the_references_own_sample_lists(G):
 
 
 def test_render_end_to_end_vs_reference(G):
-    """render() (sparse_neus_renderer.py:457-635) per chunk, exactly as the trainer's loop calls it -> the reference's images.  The hierarchical sampler
-    amplifies fp32-class SDF differences (two runs of the reference on different hardware do not agree to 1e-5 either), so: every sample list within one
-    coarse section of the reference's, every ray whose list coincides agrees as tightly as the downstream test, and HARD CAPS on the distribution of the
-    colour error -- derived from THIS comparison (HIP vs reference), not from the oracle."""
+    """render() (sparse_neus_renderer.py:457-635) per chunk, exactly as the trainer's loop calls it -> the reference's images, both sides FROM THE IMAGES.
+    The hierarchical sampler amplifies fp32-class differences: the golden file holds the REFERENCE AGAINST ITSELF on a latent volume perturbed by 3e-6 rms
+    (max 1.5e-5 -- HIP's volume differs from the reference's by less: test_volume_build_vs_reference), and that alone moves sample lists by several coarse
+    sections and 15 % of the rays by more than 1e-3 in colour at config 2.  Asserted: the colour mask exact; rays whose sample lists coincide agree as
+    tightly as the downstream test; and HIP-vs-reference stays inside the reference-vs-reference distribution -- q50 / q90 / q99 within 3x, the maximum, the
+    fraction above 1e-3 and the largest sample-list difference within 2x (caps derived from the reference, not from the oracle or from HIP's own output)."""
     for e in RU.end_to_end(G):
         show(G, "render() end to end vs REFERENCE", e)
         assert e["color_mask_mismatches"] == 0, e
-        assert e["z_err_max"] <= 1.001 * e["coarse_spacing"], e
         amp = max(1.0, e["inv_s"] / 20.0)
         assert e["color_err_max_on_coinciding_lists"] <= TOL["core_color"] * amp, e
-        if e["variance"] <= 0.3:                 # the regime the benchmark runs in; a trained inv_s sharpens every list difference into an O(1) colour difference
-            q50, q90, q99, mx = e["color_err_q50_q90_q99_max"]
-            assert mx <= TOL["e2e_color_max"], e
-            if e["rays"] >= 1000:
-                assert q99 <= TOL["e2e_color_q99"] and e["frac_rays_color_gt_1e-3"] <= TOL["e2e_frac_gt_1e3"], e
+        own = e["reference_vs_itself_on_a_noisy_volume"]
+        if own is not None:                      # (the trained-variance subset is reported, not capped: inv_s = 148 turns every list difference into an O(1) colour difference)
+            for hip, ref in zip(e["color_err_q50_q90_q99_max"][:3], own["color_err_q50_q90_q99_max"][:3]):
+                assert hip <= TOL["e2e_vs_own_quantiles"] * ref + 1e-5, e
+            assert e["color_err_q50_q90_q99_max"][3] <= TOL["e2e_vs_own_max"] * own["color_err_q50_q90_q99_max"][3], e
+            assert e["frac_rays_color_gt_1e-3"] <= TOL["e2e_vs_own_max"] * own["frac_rays_color_gt_1e-3"] + 0.02, e
+            assert e["z_err_max"] <= TOL["e2e_vs_own_max"] * own["z_err_max"], e
 
 
 def test_extract_fields_vs_reference(G):

@@ -69,7 +69,7 @@ def main():
     import platform
     import subprocess
     git = lambda *a: subprocess.run(["git", "-C", ROOT] + list(a), capture_output=True, text=True).stdout.strip()
-    out["_meta"] = {"round": tag, "commit": git("rev-parse", "--short", "HEAD"), "dirty": bool(git("status", "--porcelain", "--", "oracle", "one-2-3-45_amd")),
+    out["_meta"] = {"round": tag, "commit": git("rev-parse", "--short", "HEAD") or os.environ.get("O2345_COMMIT", ""), "dirty": bool(git("status", "--porcelain", "--", "oracle", "one-2-3-45_amd")),
                     "date_utc": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ"), "host": platform.node(), "nproc": os.cpu_count(),
                     "cpu": next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?"), "torch": torch.__version__,
                     "script": "tools/time_reference_cpu.py"}
