@@ -165,6 +165,33 @@ def pipelined_block(dev, a, inp, imgs_list, n_streams):
             "note": "throughput of K scenes in flight on several streams of ONE GPU; the contract's value / ms_per_step above is the one-stream number"}
 
 
+def trained_regime_block(dev, wt, inp, D):
+    """The regime of a TRAINED model on the benchmark's geometry: SingleVarianceNetwork far from its 0.2 initialisation (variance 0.45 /
+    0.65 -> inv_s = exp(10 v) = 90 / 665, models/fields.py:179-186; ref_trained.npz proves the kernels handle it).  Reports, from the per-sample compositing
+    weights of one whole render, which fraction of the OCCUPIED samples (the ones the colour network is evaluated on) carry a weight below 2^-24 -- colour work
+    that cannot change the image by more than 128 x 2^-24 = 7.6e-6 -- and the render time per regime.  The seeded stand-in SDF (geometric initialisation:
+    a sphere-like level set inside the volume) is crossed by the rays: rays_hitting_surface counts weights_sum > 0.5."""
+    vol = pipeline.build_volume(wt, inp["imgs"], inp["aff"], inp["origin"], D, 2.0 / (D - 1))
+    old = (wt.variance, wt.inv_s)
+    out = {"note": "occupied = sample mid-points inside kept voxels (sparse_neus_renderer.py:216-221); free-space samples carry the reference's +1e-5 and are never dropped"}
+    try:
+        for v in (0.2, 0.45, 0.65):
+            wt.variance, wt.inv_s = v, float(np.clip(np.exp(10.0 * v), 1e-6, 1e6))
+            fn = lambda: pipeline.render(wt, vol, inp["proj"], inp["cam_pos"], inp["rays_o"], inp["rays_d"], inp["near"], inp["far"], inp["qcam"])
+            o = fn()
+            occ = o["pm"] > 0
+            w = o["weights"][occ]
+            n = int(w.numel())
+            fr = lambda t: float((w < t).sum()) / max(1, n)
+            out[f"variance_{v}"] = {"inv_s": wt.inv_s, "occupied_samples": n, "rays_hitting_surface": int((o["weights_sum"] > 0.5).sum()),
+                                    "frac_occupied_with_weight_below": {"2^-24": fr(2.0 ** -24), "1e-6": fr(1e-6), "1e-5": fr(1e-5), "1e-4": fr(1e-4), "1e-3": fr(1e-3)},
+                                    "render_ms_median": median_ms(fn, reps=3)}
+            o = w = occ = None
+    finally:
+        wt.variance, wt.inv_s = old
+    return out
+
+
 def render_order_index(pm):
     """Slots (s * R + r) of the occupied mid-points in the order k_ray_finalize writes its list: wave-major (64 consecutive rays),
     sample-major inside a wave.  pm [S, R]."""
@@ -702,6 +729,7 @@ def main():
                 tf = Timer()
                 result["fp32_whole_step_ms"] = median_ms(lambda: step(wf, inp, a.vol, a.mesh_res, tf, a.ray_chunk), reps=3)
                 wf = None
+            result["trained_regime"] = trained_regime_block(dev, wt, inp, a.vol)
             result["ref_config"] = ref_config_block(dev, wt)
             torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
             result["config5"] = config5_block(dev, wt, a)

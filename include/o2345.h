@@ -43,6 +43,8 @@ const char* o2345_last_error(void);
 /* 200 = ABI 2.0 (round 4): O2345RenderIO re-laid out (sdf_mode replaces the fossil name sdf_bf16; color_blob / the VALU colour kernel removed;
  * per-ray near / far; caller-owned colour work counters; per-call scalars) and layout-checked (o2345_render_io_*), o2345_camera_terms,
  * `identity_rows` on o2345_sparse_conv3d_x3, no process-global state left in the library (the colour work counters are a caller-owned buffer). */
+/* 210 = ABI 2.1 (round 5): O2345RenderIO gains `segment_rays` (the reference's two per-CALL rules applied per segment of a fused call: a whole image
+ * behind the trainer's unchanged 512-ray chunk loop) and `weight_cull` (tolerance-bounded colour work removal); o2345_ray_composite is unchanged. */
 int o2345_version(void);
 /* Layout self-description of O2345RenderIO as THIS library was compiled (sizeof, and offsetof of every field in declaration order): a binding
  * asserts its own struct against it at load time (one-2-3-45_amd/_lib.py does) -- a field added on one side only cannot corrupt calls silently.
@@ -244,9 +246,19 @@ typedef struct O2345RenderIO {
     const float* t_rand;            /* optional [R][n_samples]: the reference's perturb > 0 jitter, drawn by the caller */
     int R, n_samples, n_importance;
     int sdf_mode;                   /* 0: exact fp32 MFMA SDF kernels; 2: split-f16 ("f16x3", fp32-class accuracy).  (ABI 1.x called this sdf_bf16.) */
+    int segment_rays;               /* 0: the call is ONE render() call of the reference.  > 0 (a multiple of 64): the R rays are consecutive render() calls of
+                                     * segment_rays rays each (the last one may be shorter) evaluated together -- the reference's two per-call rules (cat_z_vals' "more
+                                     * than one new point inside the mask", :137; render_core's "first 100 points when nothing is occupied", :222-223) are applied
+                                     * PER SEGMENT, t_rand holds the segments' draws back to back, and `scalars` becomes [ceil(R / segment_rays)][4] */
     float near, far;                /* used when near_ray == NULL */
     float sample_dist;              /* length of the last section (:484: ((far - near) / n_samples).mean()); <= 0: (far - near) / n_samples */
     float inv_s, alpha_inter_ratio, background;
+    float weight_cull;              /* 0: the colour network is evaluated on every occupied sample, like the reference.  > 0: only on occupied samples whose
+                                     * compositing weight w = alpha * T (the value `weights` returns, computed first from the SDF / gradient pass) is >= weight_cull;
+                                     * the others keep rgb = 0.  Every colour component lies in [0, 1] (a softmax blend of source pixels), so a ray's colour moves
+                                     * by at most S * weight_cull: 128 * 2^-24 = 7.6e-6 at the default 2^-24, below the 3e-5 stage tolerance.  depth, weights,
+                                     * gradients and the colour mask (valid-view counts of culled points come from the counting kernel) are unaffected.  Only samples
+                                     * BEHIND a surface qualify: in free space the reference's +1e-5 in alpha keeps w ~ 1e-5 (:349-375), those are never dropped. */
     /* outputs: per-sample arrays are sample-major [S][R] (+[,3]) */
     float* mid_z; float* dists; float* pm; float* sdf; float* grad; float* rgb; uint8_t* nviews;
     float* color; float* depth; float* weights; float* cdf; float* weights_sum; float* weights_max; float* depth_var;

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "o2345.h")
 LIB_PATH = os.environ.get("O2345_LIB") or os.path.join(HERE, "libo2345_hip.so")       # O2345_LIB: an A/B build variant (build.build_variant)
 
-ABI_VERSION = 200          # include/o2345.h: o2345_version()
+ABI_VERSION = 210          # include/o2345.h: o2345_version()
 
 _CT = {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong, "size_t": ctypes.c_size_t,
        "void": None, "double": ctypes.c_double}

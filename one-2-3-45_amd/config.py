@@ -33,3 +33,22 @@ def color_precision(p=None):
     if p not in PRECISIONS:
         raise ValueError(f"unknown precision {p!r}")
     return p
+
+
+# ---- tolerance-bounded colour work removal (include/o2345.h, O2345RenderIO.weight_cull) ----------------------------------------
+# render(): the colour network (59 % of a render call) is evaluated only on occupied samples whose compositing weight w = alpha * T -- known after the
+# SDF + gradient pass, before any colour -- is >= WEIGHT_CULL.  Colours lie in [0, 1], so a ray's colour moves by at most 128 * 2^-24 = 7.6e-6, a quarter
+# of the 3e-5 stage tolerance; depth, weights, gradients and the colour mask are untouched.  What qualifies are the samples BEHIND a surface (T ~ 0):
+# 6 % of the occupied samples at the untrained variance 0.2 (inv_s 7.4), 27 % / 47 % at a trained model's 0.45 / 0.65 (bench.py, `trained_regime`);
+# free-space samples keep the reference's +1e-5 (w ~ 1e-5) and are never dropped.  O2345_WEIGHT_CULL=0 selects the exhaustive path (every occupied
+# sample, the reference's work); both are tested.
+WEIGHT_CULL = float(os.environ.get("O2345_WEIGHT_CULL", 2.0 ** -24))
+if not (0.0 <= WEIGHT_CULL < 1.0):
+    raise ValueError(f"O2345_WEIGHT_CULL must be in [0, 1), got {WEIGHT_CULL}")
+
+
+def weight_cull(w=None):
+    w = WEIGHT_CULL if w is None else float(w)
+    if not (0.0 <= w < 1.0):
+        raise ValueError(f"weight_cull must be in [0, 1), got {w}")
+    return w

@@ -33,7 +33,7 @@ int preload_convnet();
 
 extern "C" {
 const char* o2345_last_error(void) { return o2345::g_err; }
-int o2345_version(void) { return 200; }     // 2.0: see include/o2345.h (1.5: o2345_list_sort_by_visibility; 1.4: color stats, bf16 entry removed; 1.3: o2345_conv2d family; 1.2: t_rand)
+int o2345_version(void) { return 210; }     // 2.1: segment_rays + weight_cull in O2345RenderIO; 2.0: see include/o2345.h (1.5: o2345_list_sort_by_visibility; 1.4: color stats, bf16 entry removed; 1.3: o2345_conv2d family; 1.2: t_rand)
 
 int o2345_preload(void) {
     int e, bad = 0;
@@ -67,8 +67,8 @@ int o2345_render_io_layout(size_t* offsets_host, int n) {
 #define F(name) offsetof(O2345RenderIO, name)
     static const size_t off[] = {
         F(sdf_blob), F(color_x3_blob), F(color_mfma_blob), F(vol_cl), F(maskvol), F(cmaps), F(proj), F(cam_pos), F(D), F(V), F(H), F(W),
-        F(rays_o), F(rays_d), F(near_ray), F(far_ray), F(query_cam), F(t_rand), F(R), F(n_samples), F(n_importance), F(sdf_mode),
-        F(near), F(far), F(sample_dist), F(inv_s), F(alpha_inter_ratio), F(background),
+        F(rays_o), F(rays_d), F(near_ray), F(far_ray), F(query_cam), F(t_rand), F(R), F(n_samples), F(n_importance), F(sdf_mode), F(segment_rays),
+        F(near), F(far), F(sample_dist), F(inv_s), F(alpha_inter_ratio), F(background), F(weight_cull),
         F(mid_z), F(dists), F(pm), F(sdf), F(grad), F(rgb), F(nviews), F(color), F(depth), F(weights), F(cdf), F(weights_sum), F(weights_max),
         F(depth_var), F(alpha_sum), F(grad_err), F(color_mask), F(z_vals), F(scalars), F(color_stats)};
 #undef F

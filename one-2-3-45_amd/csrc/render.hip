@@ -564,6 +564,55 @@ __global__ __launch_bounds__(64) void k_ray_composite(RayGeom g, int S, const fl
     if (r < g.R) composite_ray(g, r, S, mid_z, dists, pm, sdf, grad, rgb, nviews, inv_s, air, bg, o);
 }
 
+// ---- tolerance-bounded colour work removal (O2345RenderIO.weight_cull) ------------------------------------------------------------------------
+// After the SDF + gradient pass every compositing weight w = alpha * T is known -- it does not depend on the colours.  This pass runs composite_ray's
+// transmittance chain (the SAME functions in the same order: the w it thresholds is bit-identical to the `weights` the composite kernel returns) and
+// emits the list of the occupied samples with w >= thr: only those go through the visibility sort and the colour network.  keep[p] = 1 there, 0 on
+// every other slot (unoccupied or culled: the counting kernel supplies their valid-view counts, so the per-ray colour mask stays exact); culled occupied
+// samples get the colour 0 the composite kernel will multiply by their w < thr.
+__global__ __launch_bounds__(256) void k_ray_cull(RayGeom g, int S, const float* __restrict__ dists, const float* __restrict__ pm, const float* __restrict__ sdf,
+                                                  const float* __restrict__ grad, float inv_s, float air, float thr, float* __restrict__ keep,
+                                                  float* __restrict__ rgb, int* __restrict__ list, int* __restrict__ count) {
+    const int R = g.R;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const bool live = r < R;
+    const int rr = live ? r : R - 1;
+    const float dx = g.rays_d[3 * rr], dy = g.rays_d[3 * rr + 1], dz = g.rays_d[3 * rr + 2];
+    ValidBits bits{};
+    int cnt = 0;
+    float T = 1.f;
+    constexpr int CB = 8;
+    for (int sb = 0; sb < S; sb += CB) {
+        float bm[CB], bd[CB], bs[CB], bg[CB][3];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            const int s = sb + k < S ? sb + k : S - 1;
+            const size_t p = (size_t)s * R + rr;
+            bm[k] = pm[p]; bd[k] = dists[p]; bs[k] = sdf[p];
+            bg[k][0] = grad[3 * p]; bg[k][1] = grad[3 * p + 1]; bg[k][2] = grad[3 * p + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            if (sb + k < S) {
+                const int s = sb + k;
+                const size_t p = (size_t)s * R + rr;
+                float pc;
+                const float alpha = composite_sample_alpha(dx, dy, dz, bg[k][0], bg[k][1], bg[k][2], bm[k], bd[k], bs[k], inv_s, air, pc);
+                const float w = alpha * T;
+                T = T * (1.f - alpha + 1e-7f);
+                const bool occ = bm[k] > 0.f;
+                const bool kp = live && occ && w >= thr;
+                if (live) {
+                    keep[p] = kp ? 1.f : 0.f;
+                    if (occ && !kp) { rgb[3 * p] = 0.f; rgb[3 * p + 1] = 0.f; rgb[3 * p + 2] = 0.f; }
+                }
+                if (kp) { bits.w[s >> 5] |= 1u << (s & 31); ++cnt; }
+            }
+        }
+    }
+    append_wave(bits, S, cnt, R, rr, list, count);
+}
+
 // per-call scalars of render()'s returned dict (:586-633): sums over the rays in a FIXED order (thread t adds rays t, t + 1024, ... in fp64, then a
 // fixed LDS tree): deterministic, one workgroup, no atomics.  out[0] = alpha_sum.mean(), out[1] = alpha_sum.sum() / (R S) ("alpha_mean"),
 // out[2] = sum grad_err[.,0] / (sum grad_err[.,1] + 1e-5) ("gradient_error_fine"), out[3] = number of list entries the network kernels evaluated.
@@ -718,11 +767,17 @@ int o2345_ray_composite(const float* rays_o, const float* rays_d, int R, int S, 
 // ---- the whole render() call -----------------------------------------------------------------------------------------
 // Workspace layout (floats unless noted), S = n_samples + n_importance, NI = n_importance / 4, R rays:
 //   z[S*R] sdf[S*R] new_z[NI*R] new_sdf[NI*R] pts[3*S*R] list[S*R ints] count[64 ints] msk[S*R bytes] new_msk[NI*R bytes] wbuf[S*R] (streaming kernels only)
+//   culled list[S*R ints] (weight_cull > 0; its keep flags reuse sdf[], dead after the last merge)
 //   ... and, when the list is sorted: sorted list[S*R ints] + the workspace of o2345_list_sort_by_visibility (csrc/list_sort.hip)
-static size_t render_core_workspace_bytes(int R, int n_samples, int n_importance) {
+static size_t render_cull_list_offset(int R, int n_samples, int n_importance) {
     const size_t S = (size_t)n_samples + n_importance, NI = (size_t)(n_importance / 4 > 0 ? n_importance / 4 : 1);
     size_t bytes = ((S * 2 + NI * 2 + 3 * S + S) * (size_t)R + 64) * 4 + ((S + NI) * (size_t)R + 3) / 4 * 4;
     if ((long long)R >= knobs().ray_stream_min) bytes += S * (size_t)R * 4;
+    return (bytes + 255) / 256 * 256;
+}
+static size_t render_core_workspace_bytes(int R, int n_samples, int n_importance) {
+    const size_t S = (size_t)n_samples + n_importance;
+    const size_t bytes = render_cull_list_offset(R, n_samples, n_importance) + S * (size_t)R * 4;      // + the culled list (weight_cull > 0)
     return (bytes + 255) / 256 * 256;
 }
 // The occupied-point list is grouped by view-visibility signature only where that pays: the sort is 4 launches per 8 views and costs 0.1 - 0.25 ms
@@ -792,23 +847,45 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     ra.S = cur; ra.n_new = (int)NI; ra.count = count; ra.done = count + 8; ra.sample_dist = sample_dist;        // count was advanced by 4: slot 12
     ra.mid_z = io->mid_z; ra.dists = io->dists; ra.pts = fpts; ra.pm = io->pm; ra.o_sdf = io->sdf; ra.grad = io->grad; ra.rgb = io->rgb; ra.defaults_everywhere = 0;
     if ((rc = ray_round_launch(RM_FINALIZE, ra, nullptr, stream))) return rc;               // incl. render_core's "first 100 points" rule (round_epilogue)
+    const bool cull = io->weight_cull > 0.f;
+    const bool sorts = render_sorts_list(R, NS, NIMP, io->V);
+    int* slist = (int*)((char*)workspace + render_core_workspace_bytes(R, NS, NIMP));
+    void* sort_ws = (void*)(slist + S * RR);
     // the list grouped by view-visibility signature (stable): the colour kernel then skips every (tile, view) pair in which no point sees the view instead of
-    // 3/4 of them -- 40.0 -> 36.1 ms at 8 views, bit-identical results (csrc/list_sort.hip); only for lists long enough to pay for it (render_sorts_list)
-    if (render_sorts_list(R, NS, NIMP, io->V)) {
-        int* slist = (int*)((char*)workspace + render_core_workspace_bytes(R, NS, NIMP));
-        void* sort_ws = (void*)(slist + S * RR);
-        if ((rc = o2345_list_sort_by_visibility(fpts, list, count, (long long)(S * RR), io->proj, io->V, io->H, io->W, slist, nullptr, sort_ws,
-                                                o2345_list_sort_workspace_bytes((long long)(S * RR), io->V), stream))) return rc;
-        list = slist;
+    // 3/4 of them -- 40.0 -> 36.1 ms at 8 views, bit-identical results (csrc/list_sort.hip); only for lists long enough to pay for it (render_sorts_list).
+    // The SDF-gradient kernel does not care about the order (10.17 vs 10.15 ms): with weight culling it runs on the emission-order list and only the
+    // (shorter) culled list is sorted.
+    auto sort_list = [&](const int* in, const int* n_dev) {
+        return o2345_list_sort_by_visibility(fpts, in, n_dev, (long long)(S * RR), io->proj, io->V, io->H, io->W, slist, nullptr, sort_ws,
+                                             o2345_list_sort_workspace_bytes((long long)(S * RR), io->V), stream);
+    };
+    const int* clist = list;                     // what the colour network evaluates
+    const int* ccount = count;
+    const float* counted_elsewhere = io->pm;     // slots whose valid-view count the colour kernel writes itself
+    if (!cull && sorts) {
+        if ((rc = sort_list(list, count))) return rc;
+        list = slist; clist = slist;
     }
     if ((rc = sdf_eval(2, fpts, list, count, 0, io->sdf, io->grad))) return rc;
+    if (cull) {
+        int* list2 = (int*)((char*)workspace + render_cull_list_offset(R, NS, NIMP));
+        float* keep = sdf;                       // the workspace's SDF list is dead after the last merge
+        hipLaunchKernelGGL(k_ray_cull, dim3(cdiv(R, 256)), dim3(256), 0, s, ra.g, (int)S, io->dists, io->pm, io->sdf, io->grad, io->inv_s, io->alpha_inter_ratio,
+                           io->weight_cull, keep, io->rgb, list2, count + 1);
+        if ((rc = check_launch("ray_cull"))) return rc;
+        clist = list2; ccount = count + 1; counted_elsewhere = keep;
+        if (sorts) {
+            if ((rc = sort_list(list2, count + 1))) return rc;
+            clist = slist;
+        }
+    }
     // valid-view counts (feed the per-ray colour mask): the colour kernels write them for the points they evaluate (the occupied ones, 88 % at
     // BASELINE config 2); this pass covers the rest (four IEEE divisions per view make it VALU-bound: 0.48 ms over all points)
-    if ((rc = o2345_view_count_unlisted(fpts, (long long)S * R, io->pm, io->maskvol, io->D, io->proj, io->V, io->H, io->W, io->nviews, stream))) return rc;
+    if ((rc = o2345_view_count_unlisted(fpts, (long long)S * R, counted_elsewhere, io->maskvol, io->D, io->proj, io->V, io->H, io->W, io->nviews, stream))) return rc;
     if (io->color_x3_blob)
-        rc = o2345_color_points_x3(io->color_x3_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, io->nviews, io->color_stats, stream);
+        rc = o2345_color_points_x3(io->color_x3_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, clist, ccount, 0, io->query_cam, nullptr, io->rgb, io->nviews, io->color_stats, stream);
     else
-        rc = o2345_color_points_mfma(io->color_mfma_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, list, count, 0, io->query_cam, nullptr, io->rgb, io->nviews, io->color_stats, stream);
+        rc = o2345_color_points_mfma(io->color_mfma_blob, io->vol_cl, io->maskvol, io->D, io->cmaps, io->proj, io->cam_pos, io->V, io->H, io->W, fpts, clist, ccount, 0, io->query_cam, nullptr, io->rgb, io->nviews, io->color_stats, stream);
     if (rc) return rc;
     if ((rc = o2345_ray_composite(io->rays_o, io->rays_d, R, (int)S, io->mid_z, io->dists, io->pm, io->sdf, io->grad, io->rgb, io->nviews, io->inv_s, io->alpha_inter_ratio, io->background,
                                   io->color, io->depth, io->weights, io->cdf, io->weights_sum, io->weights_max, io->depth_var, io->alpha_sum, io->grad_err, io->color_mask, stream))) return rc;

@@ -557,12 +557,16 @@ _SCENE_KEYS = ("sdf_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos")
 
 @_on_device
 def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64, inv_s=None, alpha_inter_ratio=1.0,
-                background=1.0, query_cam=None, want_z=False, t_rand=None, sample_dist=None, want_scalars=False, color_stats=None):
+                background=1.0, query_cam=None, want_z=False, t_rand=None, sample_dist=None, want_scalars=False, color_stats=None,
+                weight_cull=None, segment_rays=0):
     """scene: dict(sdf_blob, color_x3_blob and / or color_mfma_blob, vol_cl, maskvol [D^3], cmaps, proj [V,3,4], cam_pos [V,3]).
     near / far: python floats, or two float32 tensors [R] on the device (the reference's per-ray [N_rays, 1] form; then ``sample_dist`` =
     ((far - near) / n_samples).mean() must be given, sparse_neus_renderer.py:484).
     t_rand [R, n_samples] (optional): the reference's stratified jitter of the coarse samples (perturb > 0, :506-515), drawn by the caller.
     want_scalars: also ``scalars`` [4] = (alpha_sum.mean(), alpha_sum.sum() / (R S), gradient error, evaluated points).  color_stats: color_stats_buffer().
+    weight_cull (None: config.weight_cull(), default 2^-24; 0: exhaustive like the reference): the colour network is evaluated only on occupied samples whose
+    compositing weight is >= weight_cull -- a ray's colour moves by <= (n_samples + n_importance) * weight_cull (include/o2345.h, O2345RenderIO.weight_cull).
+    segment_rays (0: one render() call): the rays are consecutive render() calls of that many rays evaluated together (O2345RenderIO.segment_rays).
     Returns dict of SAMPLE-MAJOR tensors ([S,R,...]) + per-ray results."""
     L = _lib.lib()
     R = rays_o.shape[0]
@@ -622,6 +626,8 @@ def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64,
     io.sample_dist = float(sample_dist) if sample_dist is not None else 0.0
     io.n_samples, io.n_importance = n_samples, n_importance
     io.inv_s, io.alpha_inter_ratio, io.background = float(inv_s), float(alpha_inter_ratio), float(background)
+    io.weight_cull = float(config.weight_cull(scene.get("weight_cull") if weight_cull is None else weight_cull))
+    io.segment_rays = int(segment_rays)
     io.query_cam = _p(query_cam).value
     for k, t in o.items():
         setattr(io, k, t.data_ptr())

@@ -19,7 +19,7 @@ def test_cabi_exports_every_declared_symbol():
     protos = L.parse_header()
     assert len(protos) >= 30 and "o2345_render_rays" in protos and "o2345_marching_cubes_emit" in protos
     lib = L.lib()                                    # raises if the .so is missing or a declared symbol is not exported
-    assert lib.o2345_version() == L.ABI_VERSION == 200
+    assert lib.o2345_version() == L.ABI_VERSION == 210
     assert lib.o2345_sdf_blob_floats() == pkg.weights.SDF_BLOB_FLOATS
     assert not hasattr(lib, "o2345_color_points") and "o2345_color_stats_enable" not in protos      # ABI 2.0: VALU colour kernel and library-global counters are gone
     assert lib.o2345_color_mfma_blob_floats() == pkg.weights.CM_BLOB_FLOATS
