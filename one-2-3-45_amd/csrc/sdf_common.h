@@ -20,6 +20,7 @@ constexpr int OFF_A0T = OFF_A1T + 5 * STB * 64;    // [2][STB][64]   d/d(pe)
 constexpr int OFF_MISC = OFF_A0T + 2 * STB * 64;   // b0[128] b1[128] b2[128] w2row_h[128] w2row_lat[16] (lane-half order)
 constexpr int MISC_B0 = 0, MISC_B1 = 128, MISC_B2 = 256, MISC_W2H = 384, MISC_W2L = 512, MISC_SIZE = 528;
 constexpr int BLOB_F32_FLOATS = OFF_MISC + MISC_SIZE;
+constexpr int OFFX_MISC = BLOB_F32_FLOATS;         // the split-f16 kernels' MISC block: b0, b1 in the t domain (weights.py SOFTPLUS_SCALE), the rest as above
 // reserved section (the bf16 operand copies of the bf16 mode removed in round 3): [block][step][64 lanes][4 floats]; the split-f16 offsets follow it
 constexpr int STH1 = 9;                                  // layer-1 k steps of 16 (8 hidden + 1 latent)
 constexpr int STHB = 8;                                  // backward k steps of 16 (128 upstream neurons)
@@ -105,6 +106,39 @@ __device__ __forceinline__ f32x2 softplus100_pair(f32x2 a, f32x2& dsig) {
     q[0] = __builtin_copysignf(q[0], a[0]); q[1] = __builtin_copysignf(q[1], a[1]);
     dsig = q + 0.5f;
     return __builtin_elementwise_fma(l, f32x2{0.00693147180559945309f, 0.00693147180559945309f}, m);
+}
+
+// ---- the same in the t domain (csrc/sdf_mlp_x3.hip): t = 100 a / ln 2 arrives from the matrix cores (the factor is folded into the packed operands,
+// weights.py SOFTPLUS_SCALE) and the activation leaves as s' = softplus(a) * 100 / ln 2 = max(t, 0) + log2(1 + 2^-|t|): no multiply in front, a plain add
+// at the end -- 5 vector instructions per value instead of 6.  For t > 24, fl(1 + 2^-t) == 1 and s' == t exactly (torch's threshold branch, 100 a > 20
+// <=> t > 28.9).  softplus'(a) = sigmoid(100 a) = sigmoid(t ln 2) = 1 / (1 + 2^-t).
+constexpr float SOFTPLUS_INV_SCALE = 0.00693147180559945309f;                           // ln 2 / 100: applied ONCE per point, to the SDF row's hidden sum
+__device__ __forceinline__ f32x2 softplus_t_pair(f32x2 t) {
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(-__builtin_fabsf(t[0]));
+    e[1] = __builtin_amdgcn_exp2f(-__builtin_fabsf(t[1]));
+    const f32x2 u = e + 1.f;
+    f32x2 l, m;
+    l[0] = __builtin_amdgcn_logf(u[0]); l[1] = __builtin_amdgcn_logf(u[1]);
+    m[0] = fmaxf(t[0], 0.f); m[1] = fmaxf(t[1], 0.f);
+    return l + m;
+}
+__device__ __forceinline__ f32x2 softplus_t_pair(f32x2 t, f32x2& dsig) {
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(-__builtin_fabsf(t[0]));
+    e[1] = __builtin_amdgcn_exp2f(-__builtin_fabsf(t[1]));
+    const f32x2 u = e + 1.f;
+    f32x2 l, m, ru;
+    l[0] = __builtin_amdgcn_logf(u[0]); l[1] = __builtin_amdgcn_logf(u[1]);
+    ru[0] = __builtin_amdgcn_rcpf(u[0]); ru[1] = __builtin_amdgcn_rcpf(u[1]);
+    m[0] = fmaxf(t[0], 0.f); m[1] = fmaxf(t[1], 0.f);
+    f32x2 q = ru - 0.5f;
+    q[0] = __builtin_copysignf(q[0], t[0]); q[1] = __builtin_copysignf(q[1], t[1]);
+    dsig = q + 0.5f;
+    return l + m;
+}
+__device__ __forceinline__ float softplus_t_d(float t) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-t));
 }
 
 // derivative only (the gradient kernels re-evaluate layer 0 just for this): sigmoid(100 a) = 1 / (1 + exp(-100 a))

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(512) void k_sdf_mlp_x3(SdfArgs a) {
     constexpr int L_A0 = 0, L_A1 = N_A0, L_MISC = N_A0 + N_A1;
     for (int i = threadIdx.x * 4; i < N_A0 + N_A1; i += blockDim.x * 4)           // the two sections are adjacent in the blob
         *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(a.blob + OFFX_A0 + i);
-    for (int i = threadIdx.x; i < MISC_SIZE; i += blockDim.x) lds[L_MISC + i] = a.blob[OFF_MISC + i];
+    for (int i = threadIdx.x; i < MISC_SIZE; i += blockDim.x) lds[L_MISC + i] = a.blob[OFFX_MISC + i];           // b0, b1 in the t domain
     __syncthreads();
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const float m1 = opaque_minus_one();
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(512) void k_sdf_mlp_x3(SdfArgs a) {
             float hv[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const f32x2 sp = softplus100_pair(f32x2{acc[nb][r], acc[nb][r + 1]});
+                const f32x2 sp = softplus_t_pair(f32x2{acc[nb][r], acc[nb][r + 1]});
                 hv[r] = sp[0]; hv[r + 1] = sp[1];
             }
             hb[2 * nb] = split8(hv, m1); hb[2 * nb + 1] = split8(hv + 8, m1);
@@ -186,15 +186,16 @@ __global__ __launch_bounds__(512) void k_sdf_mlp_x3(SdfArgs a) {
         for (int s = 0; s < 8; ++s) mma_x3<4, STH1>(acc, A1, lane, s, hb[s]);
         mma_x3<4, STH1>(acc, A1, lane, 8, split8(lat, m1));
         // ---- SDF output row: fp32 dot product ------------------------------------------------------------------------------------------
-        float y0 = 0.f;
+        float yh = 0.f;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const f32x2 sp = softplus100_pair(f32x2{acc[nb][r], acc[nb][r + 1]});
-                y0 = fmaf(misc[MISC_W2H + (nb * 16 + r) * 2 + h], sp[0], y0);
-                y0 = fmaf(misc[MISC_W2H + (nb * 16 + r + 1) * 2 + h], sp[1], y0);
+                const f32x2 sp = softplus_t_pair(f32x2{acc[nb][r], acc[nb][r + 1]});
+                yh = fmaf(misc[MISC_W2H + (nb * 16 + r) * 2 + h], sp[0], yh);
+                yh = fmaf(misc[MISC_W2H + (nb * 16 + r + 1) * 2 + h], sp[1], yh);
             }
+        float y0 = yh * SOFTPLUS_INV_SCALE;          // the hidden activations are s' = softplus * 100 / ln 2: the factor comes off once per point
 #pragma unroll
         for (int t = 0; t < 8; ++t) y0 += misc[MISC_W2L + 8 * h + t] * lat[t];
         y0 += __shfl_xor(y0, 32);
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(512) void k_sdf_grad_x3(SdfArgs a) {
     constexpr int L_A0 = 0, L_A1 = N_A0, L_A1T = N_A0 + N_A1, L_MISC = N_A0 + N_A1 + N_A1T3;
     for (int i = threadIdx.x * 4; i < L_MISC; i += blockDim.x * 4)                // the three sections are adjacent in the blob
         *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(a.blob + OFFX_A0 + i);
-    for (int i = threadIdx.x; i < MISC_SIZE; i += blockDim.x) lds[L_MISC + i] = a.blob[OFF_MISC + i];
+    for (int i = threadIdx.x; i < MISC_SIZE; i += blockDim.x) lds[L_MISC + i] = a.blob[OFFX_MISC + i];           // b0, b1 in the t domain
     __syncthreads();
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const float m1 = opaque_minus_one();
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(512) void k_sdf_grad_x3(SdfArgs a) {
             float hv[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const f32x2 sp = softplus100_pair(f32x2{acc[nb][r], acc[nb][r + 1]});
+                const f32x2 sp = softplus_t_pair(f32x2{acc[nb][r], acc[nb][r + 1]});
                 hv[r] = sp[0]; hv[r + 1] = sp[1];
             }
             hb[2 * nb] = split8(hv, m1); hb[2 * nb + 1] = split8(hv + 8, m1);
@@ -355,20 +356,23 @@ __global__ __launch_bounds__(512) void k_sdf_grad_x3(SdfArgs a) {
         mma_x3<4, STH1>(acc, A1, lane, 8, latx);
         AReg<2> tcur = a_fetch<2, STHB>(rs, OFFX_A1T, lane, 3, 0);             // first streamed operands of the backward pass
         Split8 g1x[8];                  // d sdf / d a1 = w2row * softplus'(a1), split, as the backward k-step operands
-        float y0 = ylat;
+        // (t domain, weights.py SOFTPLUS_SCALE: d sdf / d a1 = w2row * softplus'(a1) stays in the a domain -- the backward operands are the unscaled ones --
+        // and the SDF row's hidden sum over s' = softplus * 100 / ln 2 loses the factor once per point)
+        float yh = 0.f;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             float gv[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 f32x2 d;
-                const f32x2 v = softplus100_pair(f32x2{acc[nb][r], acc[nb][r + 1]}, d);
+                const f32x2 v = softplus_t_pair(f32x2{acc[nb][r], acc[nb][r + 1]}, d);
                 const float w2a = misc[MISC_W2H + (nb * 16 + r) * 2 + h], w2b = misc[MISC_W2H + (nb * 16 + r + 1) * 2 + h];
-                y0 = fmaf(w2a, v[0], y0); y0 = fmaf(w2b, v[1], y0);
+                yh = fmaf(w2a, v[0], yh); yh = fmaf(w2b, v[1], yh);
                 gv[r] = w2a * d[0]; gv[r + 1] = w2b * d[1];
             }
             g1x[2 * nb] = split8(gv, m1); g1x[2 * nb + 1] = split8(gv + 8, m1);
         }
+        float y0 = fmaf(yh, SOFTPLUS_INV_SCALE, ylat);
         y0 += __shfl_xor(y0, 32);
         y0 += misc[MISC_B2];
         if (live && h == 0) a.out_sdf[slot] = a.sign * y0;
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(512) void k_sdf_grad_x3(SdfArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             float gv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gv[r] = g[nb][r] * softplus100_d(a0r[0][r]);
+            for (int r = 0; r < 16; ++r) gv[r] = g[nb][r] * softplus_t_d(a0r[0][r]);
             mma_x3_regs<2, 2>(gp, 0, ta, split8(gv, m1));
             mma_x3_regs<2, 2>(gp, 0, tb, split8(gv + 8, m1));
             __builtin_amdgcn_sched_barrier(0);

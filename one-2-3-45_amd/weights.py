@@ -134,9 +134,17 @@ OFF_A0T = OFF_A1T + 5 * STB * 64
 OFF_MISC = OFF_A0T + 2 * STB * 64
 MISC_B0, MISC_B1, MISC_B2, MISC_W2H, MISC_W2L, MISC_SIZE = 0, 128, 256, 384, 512, 528
 SDF_F32_FLOATS = OFF_MISC + MISC_SIZE
-# reserved: former bf16 copies of the wide-layer operands ([block][k-step of 16][64 lanes][8 bf16 = 4 floats]); the offsets of the split-f16 sections depend on it
+# reserved: former bf16 copies of the wide-layer operands ([block][k-step of 16][64 lanes][8 bf16 = 4 floats]); the offsets of the split-f16 sections depend on it.
+# Its first MISC_SIZE floats hold the split-f16 kernels' own MISC block (OFFX_MISC): the same rows with b0 and b1 in the SOFTPLUS_SCALE domain (below).
 STH1, STHB = 9, 8
 OFFH_A1 = SDF_F32_FLOATS
+OFFX_MISC = OFFH_A1
+# Softplus(beta = 100) on the hardware exp2 / log2 units is  softplus(a) = (ln 2 / 100) (max(t, 0) + log2(1 + 2^-|t|)),  t = a * 100 / ln 2.  The split-f16
+# kernels keep every pre-activation in the t domain and every hidden activation as s' = softplus(a) * 100 / ln 2: the factor is folded into the packed
+# operands in float64 before they are rounded -- layer 0's weights and bias and layer 1's LATENT columns and bias carry 100 / ln 2, layer 1's hidden
+# columns nothing (the factors of s' and of t cancel), the SDF row's hidden part is summed unscaled and multiplied by ln 2 / 100 once per point.  One
+# multiply less per softplus (5 instead of 6 instructions; 256 softplus per point), no multiply-add at its end.  The backward operands are unchanged.
+SOFTPLUS_SCALE = 100.0 / np.log(2.0)
 OFFH_A1T = OFFH_A1 + 4 * STH1 * 64 * 4
 OFFH_A0T = OFFH_A1T + 5 * STHB * 64 * 4
 SDF_BF16_END = OFFH_A0T + 2 * STHB * 64 * 4
@@ -274,16 +282,24 @@ def pack_sdf_blob(W):
     F_A1 = np.zeros((4, STH1, 64, 8), np.float32)
     F_A1T = np.zeros((5, STHB, 64, 8), np.float32)
     F_A0T = np.zeros((2, STHB, 64, 8), np.float32)
+    c = SOFTPLUS_SCALE
+    w0s = (np.asarray(w0, np.float64) * c).astype(np.float32)                     # layer 0 in the t domain
+    w1s = np.asarray(w1, np.float32).copy()
+    w1s[:, 128:] = (np.asarray(w1[:, 128:], np.float64) * c).astype(np.float32)   # layer 1: hidden columns as they are, latent columns x c
     for st in range(STX0):
         for t in range(8):
             cols = np.array([pe_index(8 * st + t, h) if 8 * st + t < 20 else -1 for h in (0, 1)])[h_of]
             for nb in range(4):
-                F_A0[nb, st, :, t] = np.where(cols >= 0, w0[nb * 32 + i_of, np.maximum(cols, 0)], 0.0)
+                F_A0[nb, st, :, t] = np.where(cols >= 0, w0s[nb * 32 + i_of, np.maximum(cols, 0)], 0.0)
     for st in range(STH1):
         for t in range(8):
             cols = np.array([kcol_h(st, h, t) for h in (0, 1)])[h_of]
             for nb in range(4):
-                F_A1[nb, st, :, t] = w1[nb * 32 + i_of, cols]
+                F_A1[nb, st, :, t] = w1s[nb * 32 + i_of, cols]
+    miscx = blob[OFFX_MISC:OFFX_MISC + MISC_SIZE]
+    miscx[:] = misc
+    miscx[MISC_B0:MISC_B0 + 128] = (misc[MISC_B0:MISC_B0 + 128].astype(np.float64) * c).astype(np.float32)
+    miscx[MISC_B1:MISC_B1 + 128] = (misc[MISC_B1:MISC_B1 + 128].astype(np.float64) * c).astype(np.float32)
     for st in range(STHB):
         for t in range(8):
             n = np.array([kcol_h(st, h, t) for h in (0, 1)])[h_of]      # downstream neuron supplying this k row
@@ -321,7 +337,7 @@ def pack_sparse_conv_x3(K):
 
 def sdf_grid_tables(W, R):
     """Layer 0 of the SDF network tabulated per axis for the lattice linspace(-1,1,R)^3 (csrc/sdf_mlp_x3.hip, TAB form): the 39-wide embedding is
-    separable, so W0 . PE(x,y,z) = Tx[ix] + Ty[iy] + Tz[iz] with T_d[i][n] = w0[n,d] p + sum_k w0[n,3+6k+d] sin(2^k p) + w0[n,6+6k+d] cos(2^k p),
+    separable, so (100 / ln 2) W0 . PE(x,y,z) = Tx[ix] + Ty[iy] + Tz[iz] with T_d[i][n] = w0[n,d] p + sum_k w0[n,3+6k+d] sin(2^k p) + w0[n,6+6k+d] cos(2^k p),
     p = linspace(-1,1,R)[i] as fp32 (the value the kernels use), evaluated in float64 and rounded once.
     -> (tab_axes float32 [3,R,128], bias float32 [128]), columns in the kernels' lane order [wave half][accumulator block * 16 + register]."""
     import torch
@@ -336,7 +352,8 @@ def sdf_grid_tables(W, R):
             f = float(1 << k)
             t += np.outer(np.sin(p * f), w0[:, 3 + 6 * k + d]) + np.outer(np.cos(p * f), w0[:, 6 + 6 * k + d])
         tabs[d] = t[:, order]
-    return tabs.astype(np.float32), np.asarray(W["b0"], np.float32)[order].copy()
+    # the split-f16 kernels keep layer 0's pre-activation in the t domain (SOFTPLUS_SCALE above): tables and bias carry 100 / ln 2
+    return (tabs * SOFTPLUS_SCALE).astype(np.float32), (np.asarray(W["b0"], np.float64)[order] * SOFTPLUS_SCALE).astype(np.float32)
 
 
 # ---- seeded initialisers (stand-ins for the reference's, same distributions) ----------------------------------------

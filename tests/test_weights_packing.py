@@ -175,7 +175,8 @@ def test_shared_rows_matrix_operand_of_color_pts(pkg):
 
 def test_sdf_grid_tables_are_the_separable_first_layer(pkg):
     """weights.sdf_grid_tables (the TAB form of csrc/sdf_mlp_x3.hip): on the lattice linspace(-1,1,R)^3 the first layer of the SDF network is
-    b0 + Tx[ix] + Ty[iy] + Tz[iz]; checked against W0 . embed(p) + b0 of the oracle's embedding, columns in the kernels' lane order."""
+    b0 + Tx[ix] + Ty[iy] + Tz[iz] -- stored in the kernels' t domain, i.e. times weights.SOFTPLUS_SCALE = 100 / ln 2; checked against W0 . embed(p) + b0 of
+    the oracle's embedding, columns in the kernels' lane order."""
     W = _weights(pkg)
     for R in (17, 64):
         axes, bias = pkg.weights.sdf_grid_tables(W, R)
@@ -187,6 +188,6 @@ def test_sdf_grid_tables_are_the_separable_first_layer(pkg):
         idx = rng.integers(0, R, (300, 3))
         p = torch.stack([lin[idx[:, 0]], lin[idx[:, 1]], lin[idx[:, 2]]], -1)
         ref = (O.embed(p).double() @ torch.from_numpy(W["w0"]).double().T + torch.from_numpy(W["b0"]).double()).numpy()[:, order]
-        got = axes[0][idx[:, 0]].astype(np.float64) + axes[1][idx[:, 1]] + axes[2][idx[:, 2]] + bias
+        got = (axes[0][idx[:, 0]].astype(np.float64) + axes[1][idx[:, 1]] + axes[2][idx[:, 2]] + bias) / pkg.weights.SOFTPLUS_SCALE
         assert np.abs(got - ref).max() < 5e-6
 

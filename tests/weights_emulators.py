@@ -127,7 +127,13 @@ def emulate_sdf_blob_x3(blob, pts, lat):
                 acc[nb] = mfma16(A[nb, st, 0], bh, acc[nb])
         return acc
 
-    misc = blob[OFF_MISC:OFF_MISC + MISC_SIZE].astype(np.float64)
+    from importlib import import_module
+    Wm = import_module("one-2-3-45_amd.weights")
+    misc = blob[Wm.OFFX_MISC:Wm.OFFX_MISC + MISC_SIZE].astype(np.float64)          # b0, b1 in the t domain (weights.SOFTPLUS_SCALE)
+    c_scale = Wm.SOFTPLUS_SCALE
+
+    def softplus(t):                            # s' = softplus(a) * 100 / ln 2 from t = 100 a / ln 2: max(t, 0) + log2(1 + 2^-|t|)
+        return np.maximum(t, 0.0) + np.log2(1.0 + np.exp2(-np.abs(t)))
     pe = np.zeros((64, 24))
     for t in range(9):
         c = 9 * h + t
@@ -143,7 +149,7 @@ def emulate_sdf_blob_x3(blob, pts, lat):
                lambda st: h0[st >> 1][:, 8 * (st & 1):8 * (st & 1) + 8] if st < 8 else latl)
     h1 = [softplus(a) for a in a1]
     w2h = [np.stack([misc[MISC_W2H + (nb * 16 + r) * 2 + h] for r in range(16)], 1) for nb in range(4)]
-    part = sum((w2h[nb] * h1[nb]).sum(1) for nb in range(4)) + sum(misc[MISC_W2L + 8 * h + t] * latl[:, t] for t in range(8))
+    part = sum((w2h[nb] * h1[nb]).sum(1) for nb in range(4)) / c_scale + sum(misc[MISC_W2L + 8 * h + t] * latl[:, t] for t in range(8))
     sdf = np.zeros(P)
     for l in lane[live & (h == 0)]:
         sdf[j[l]] = part[l] + part[l + 32] + misc[MISC_B2]
