@@ -173,12 +173,12 @@ def test_sdf_lattice_with_tabulated_layer0(dev, ops, R):
     rng = np.random.default_rng(R)
     idx = torch.from_numpy(rng.integers(0, R, (500, 3)))
     pe = O.embed(torch.stack([lin[idx[:, 0]], lin[idx[:, 1]], lin[idx[:, 2]]], -1), 6).double()
-    ref = (pe @ W["w0"].double().T + W["b0"].double())[:, order]                       # W0 . PE(x, y, z) + b0 in the kernels' lane order
+    ref = (pe @ W["w0"].double().T + W["b0"].double())[:, order] * Wn.SOFTPLUS_SCALE   # W0 . PE(x, y, z) + b0 in the kernels' lane order and t domain (x 100 / ln 2)
     got = (torch.from_numpy(axes[0])[idx[:, 0]].double() + torch.from_numpy(axes[1])[idx[:, 1]].double() + torch.from_numpy(axes[2])[idx[:, 2]].double()
            + torch.from_numpy(bias).double())
-    assert float((got - ref).abs().max()) < 5e-6
+    assert float((got - ref).abs().max()) < 5e-6 * Wn.SOFTPLUS_SCALE
     tabs = ops.sdf_grid_tables(torch.from_numpy(axes).to(dev), torch.from_numpy(bias).to(dev))
-    assert float((tabs[0].view(R, R, 128)[idx[:, 0], idx[:, 1]].cpu().double() + tabs[1][idx[:, 2]].cpu().double() - ref).abs().max()) < 5e-6
+    assert float((tabs[0].view(R, R, 128)[idx[:, 0], idx[:, 1]].cpu().double() + tabs[1][idx[:, 2]].cpu().double() - ref).abs().max()) < 5e-6 * Wn.SOFTPLUS_SCALE
     u_tab = ops.sdf_mlp(d["sdf_blob"], d["vol_cl"], None, variant=0, grid_R=R, sign=-1.0, precision="f16x3", grid_tables=tabs)["sdf"]
     u_pts = ops.sdf_mlp(d["sdf_blob"], d["vol_cl"], None, variant=0, grid_R=R, sign=-1.0, precision="f16x3")["sdf"]
     ref = O.sdf_grid(s["dense"][0], W, R)
