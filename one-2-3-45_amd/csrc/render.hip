@@ -47,12 +47,15 @@ __global__ __launch_bounds__(256) void k_ray_coarse(RayGeom g, float near, float
 // prefix): no block barrier and 1/S of the atomics of a per-sample reservation.
 struct ValidBits { unsigned w[8]; };                 // up to 256 samples per ray
 __device__ __forceinline__ void append_wave(const ValidBits& bits, int n_samples, int my_count, int R, int r,
-                                            int* __restrict__ list, int* __restrict__ count) {
+                                            int* __restrict__ list, int* __restrict__ count, int* __restrict__ seg_cnt = nullptr, int seg_rays = 0) {
     int total = my_count;
 #pragma unroll
     for (int off = 32; off; off >>= 1) total += __shfl_xor(total, off);
     int base = 0;
-    if ((threadIdx.x & 63) == 0 && total) base = atomicAdd(count, total);
+    if ((threadIdx.x & 63) == 0 && total) {
+        base = atomicAdd(count, total);
+        if (seg_cnt) atomicAdd(seg_cnt + r / seg_rays, total);     // a wave's 64 consecutive rays lie in ONE segment (seg_rays is a multiple of 64); lane 0's ray is live when total > 0
+    }
     base = __shfl(base, 0);
     if (!total) return;
     const unsigned long long lt = (1ull << (threadIdx.x & 63)) - 1ull;
@@ -96,7 +99,14 @@ struct RoundArgs {
     float sample_dist;
     float* mid_z; float* dists; float* pts; float* pm; float* o_sdf; float* grad; float* rgb; int defaults_everywhere;
     int merge_all_lists;                             // finalize + merge: also write the merged sdf / occupancy lists back (nobody reads them after the last round)
+    // O2345RenderIO.segment_rays: the rays are consecutive render() calls of seg_rays rays evaluated together; the two per-call rules per segment
+    int seg_rays, n_seg;                             // 0: the launch is one call
+    int* seg_cnt;                                    // [n_seg] zeroed: list entries this round appends, per segment
+    const int* seg_prev;                             // [n_seg] the PREVIOUS up-sampling round's counts: its new samples keep sdf = 100 where <= 1 (cat_z_vals :137)
 };
+// cat_z_vals' rule in segment mode: the SDF kernel has evaluated every listed new sample (at most ONE too many per segment); the merge that consumes
+// them reads 100 instead wherever the sample's segment had at most one new sample inside the mask -- the value the reference leaves there.
+__device__ __forceinline__ bool seg_keeps_default(const RoundArgs& a, int r) { return a.seg_prev && a.seg_prev[r / a.seg_rays] <= 1; }
 
 // The reference's two per-CALL rules on the emitted list, applied by the round kernel itself instead of a one-thread launch each (six launches of the
 // 22 of a 512-ray chunk): the workgroup that finishes LAST (a.done counts finished workgroups) sees the final count and
@@ -112,11 +122,22 @@ struct RoundArgs {
 template <int MODE>
 __device__ __forceinline__ void round_epilogue(const RoundArgs& a, int S) {
     if (!a.done || MODE == RM_MERGE_ONLY) return;    // kernel argument: uniform over the launch
+    if (a.seg_rays && MODE == RM_UPSAMPLE) return;   // segment mode: the merge that consumes the samples applies the rule (seg_keeps_default)
     __shared__ int last;
     __syncthreads();                                 // every append of this workgroup has returned its base
     if (threadIdx.x == 0) last = atomicAdd(a.done, 1) == (int)gridDim.x - 1;
     __syncthreads();
     if (!last) return;
+    if (a.seg_rays) {                                // render_core's rule per segment: a segment without any occupied point evaluates its first ray's samples 0..99
+        const int n = 100 < S ? 100 : S;
+        for (int k = threadIdx.x; k < a.n_seg; k += blockDim.x) {
+            if (atomicAdd(a.seg_cnt + k, 0) >= 1) continue;
+            const int base = atomicAdd(a.count, n);
+            for (int t = 0; t < n; ++t) a.list[base + t] = t * a.g.R + k * a.seg_rays;
+            atomicExch(a.seg_cnt + k, n);             // the segment's "evaluated points" (scalars[3])
+        }
+        return;
+    }
     const int c = atomicAdd(a.count, 0);
     if (MODE == RM_UPSAMPLE) {
         if (threadIdx.x == 0 && c <= 1) atomicExch(a.count, 0);
@@ -182,6 +203,10 @@ __global__ __launch_bounds__(256) void k_ray_stream(RoundArgs a, float* __restri
             ns[j] = z_only ? 0.f : a.new_sdf[(size_t)j * R + rr];
             nt[j] = (a.new_msk && !z_only) ? a.new_msk[(size_t)j * R + rr] : 0u;
         }
+        if (!z_only && seg_keeps_default(a, rr)) {
+#pragma unroll
+            for (int j = 0; j < NFIX; ++j) ns[j] = 100.f;
+        }
         if (MODE == RM_UPSAMPLE && a.msk && !a.new_msk) {
 #pragma unroll
             for (int j = 0; j < NFIX; ++j) {
@@ -233,7 +258,7 @@ __global__ __launch_bounds__(256) void k_ray_stream(RoundArgs a, float* __restri
                 }
             }
         }
-        append_wave(bits, a.n_imp, cnt, R, r, a.list, a.count);
+        append_wave(bits, a.n_imp, cnt, R, r, a.list, a.count, a.seg_cnt, a.seg_rays);
     } else if (MODE == RM_FINALIZE) {
         ValidBits bits{};
         int cnt = 0;
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(256) void k_ray_stream(RoundArgs a, float* __restri
                 }
             }
         }
-        append_wave(bits, S, cnt, R, r, a.list, a.count);
+        append_wave(bits, S, cnt, R, r, a.list, a.count, a.seg_cnt, a.seg_rays);
     }
     round_epilogue<MODE>(a, S);
 }
@@ -326,7 +351,7 @@ __global__ __launch_bounds__(64) void k_ray_group(RoundArgs a) {
     } else {
         // new block: lane j holds new sample j
         const float nzj = a.new_z[(size_t)l * R + rr];
-        const float nsj = a.new_sdf[(size_t)l * R + rr];
+        const float nsj = (!(MODE == RM_FINALIZE && !a.merge_all_lists) && seg_keeps_default(a, rr)) ? 100.f : a.new_sdf[(size_t)l * R + rr];
         float ntj = 0.f;
         if (need_mask || a.msk) ntj = a.new_msk ? (float)a.new_msk[(size_t)l * R + rr] : (need_mask ? mask_of(nzj) : 0.f);
         xA[l] = nzj;
@@ -432,7 +457,10 @@ __global__ __launch_bounds__(64) void k_ray_group(RoundArgs a) {
             const unsigned long long bm = __ballot(valid);
             if (bm) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(a.count, __popcll(bm));
+                if (lane == 0) {
+                    base = atomicAdd(a.count, __popcll(bm));
+                    if (a.seg_cnt) atomicAdd(a.seg_cnt + (blockIdx.x * GR) / a.seg_rays, __popcll(bm));     // the wave's four rays lie in one segment
+                }
                 base = __shfl(base, 0);
                 if (valid) a.list[base + __popcll(bm & lt)] = t * R + r;
             }
@@ -462,7 +490,10 @@ __global__ __launch_bounds__(64) void k_ray_group(RoundArgs a) {
             const unsigned long long bm = __ballot(occ);
             if (bm) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(a.count, __popcll(bm));
+                if (lane == 0) {
+                    base = atomicAdd(a.count, __popcll(bm));
+                    if (a.seg_cnt) atomicAdd(a.seg_cnt + (blockIdx.x * GR) / a.seg_rays, __popcll(bm));
+                }
                 base = __shfl(base, 0);
                 if (occ) a.list[base + __popcll(bm & lt)] = smp * R + r;
             }
@@ -537,16 +568,17 @@ __global__ __launch_bounds__(64) void k_ray_composite_group(RayGeom g, int S, co
 
 // cat_z_vals for a block size other than NFIX: the plain per-ray merge on the global lists (render_math.h merge_ray), occupancy bytes along
 __global__ __launch_bounds__(64) void k_ray_merge_any(int R, float* z, float* sdf, uint8_t* msk, int S, const float* new_z, const float* new_sdf,
-                                                      const uint8_t* new_msk, int n_new) {
+                                                      const uint8_t* new_msk, int n_new, const int* seg_prev, int seg_rays) {
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= R) return;
+    const bool keep_default = seg_prev && seg_prev[r / seg_rays] <= 1;         // cat_z_vals' rule per segment (seg_keeps_default)
     constexpr int NMAX = 32;
     float nz[NMAX], ns[NMAX];
     unsigned nt[NMAX];
     for (int base = 0; base < n_new; base += NMAX) {
         const int nb = n_new - base < NMAX ? n_new - base : NMAX;
         for (int j = 0; j < nb; ++j) {
-            nz[j] = new_z[(size_t)(base + j) * R + r]; ns[j] = new_sdf[(size_t)(base + j) * R + r];
+            nz[j] = new_z[(size_t)(base + j) * R + r]; ns[j] = keep_default ? 100.f : new_sdf[(size_t)(base + j) * R + r];
             nt[j] = new_msk ? new_msk[(size_t)(base + j) * R + r] : 0u;
         }
         GlobalMergeTag a{z, sdf, msk, (size_t)R, r};
@@ -616,9 +648,13 @@ __global__ __launch_bounds__(256) void k_ray_cull(RayGeom g, int S, const float*
 // per-call scalars of render()'s returned dict (:586-633): sums over the rays in a FIXED order (thread t adds rays t, t + 1024, ... in fp64, then a
 // fixed LDS tree): deterministic, one workgroup, no atomics.  out[0] = alpha_sum.mean(), out[1] = alpha_sum.sum() / (R S) ("alpha_mean"),
 // out[2] = sum grad_err[.,0] / (sum grad_err[.,1] + 1e-5) ("gradient_error_fine"), out[3] = number of list entries the network kernels evaluated.
-__global__ __launch_bounds__(1024) void k_ray_scalars(int R, int S, const float* __restrict__ alpha_sum, const float* __restrict__ grad_err,
-                                                      const int* __restrict__ count, float* __restrict__ out) {
+// Segment mode (seg_rays > 0): workgroup k reduces the rays of segment k in the order a call on that segment alone would -> out[k][0..3].
+__global__ __launch_bounds__(1024) void k_ray_scalars(int R_all, int S, const float* __restrict__ alpha_sum, const float* __restrict__ grad_err,
+                                                      const int* __restrict__ count, float* __restrict__ out, int seg_rays) {
     __shared__ double red[3][1024];
+    const int r0 = seg_rays ? (int)blockIdx.x * seg_rays : 0;
+    const int R = seg_rays ? (R_all - r0 < seg_rays ? R_all - r0 : seg_rays) : R_all;
+    alpha_sum += r0; grad_err += 2 * (size_t)r0; count += seg_rays ? blockIdx.x : 0; out += 4 * (size_t)blockIdx.x;
     double a = 0.0, b = 0.0, c = 0.0;
     for (int r = threadIdx.x; r < R; r += 1024) { a += (double)alpha_sum[r]; b += (double)grad_err[2 * r]; c += (double)grad_err[2 * r + 1]; }
     red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = c;
@@ -674,7 +710,8 @@ static int ray_round_launch(int mode, RoundArgs a, float* wbuf /* [rows][R] scra
     hipStream_t s = (hipStream_t)stream;
     const int R = a.g.R;
     if (a.n_new > 0 && a.n_new != NFIX) {
-        hipLaunchKernelGGL(k_ray_merge_any, dim3(cdiv(R, 64)), dim3(64), 0, s, R, a.z, a.sdf, a.msk, a.S, a.new_z, a.new_sdf, a.new_msk, a.n_new);
+        hipLaunchKernelGGL(k_ray_merge_any, dim3(cdiv(R, 64)), dim3(64), 0, s, R, a.z, a.sdf, a.msk, a.S, a.new_z, a.new_sdf, a.new_msk, a.n_new, a.seg_prev, a.seg_rays);
+        a.seg_prev = nullptr;                    // applied
         a.S += a.n_new;
         a.n_new = 0;
         if (mode == RM_MERGE_ONLY) return check_launch("ray_merge");
@@ -768,6 +805,7 @@ int o2345_ray_composite(const float* rays_o, const float* rays_d, int R, int S, 
 // Workspace layout (floats unless noted), S = n_samples + n_importance, NI = n_importance / 4, R rays:
 //   z[S*R] sdf[S*R] new_z[NI*R] new_sdf[NI*R] pts[3*S*R] list[S*R ints] count[64 ints] msk[S*R bytes] new_msk[NI*R bytes] wbuf[S*R] (streaming kernels only)
 //   culled list[S*R ints] (weight_cull > 0; its keep flags reuse sdf[], dead after the last merge)
+//   segment counters[5][R/64 + 1 ints] (segment_rays > 0)
 //   ... and, when the list is sorted: sorted list[S*R ints] + the workspace of o2345_list_sort_by_visibility (csrc/list_sort.hip)
 static size_t render_cull_list_offset(int R, int n_samples, int n_importance) {
     const size_t S = (size_t)n_samples + n_importance, NI = (size_t)(n_importance / 4 > 0 ? n_importance / 4 : 1);
@@ -775,9 +813,13 @@ static size_t render_cull_list_offset(int R, int n_samples, int n_importance) {
     if ((long long)R >= knobs().ray_stream_min) bytes += S * (size_t)R * 4;
     return (bytes + 255) / 256 * 256;
 }
-static size_t render_core_workspace_bytes(int R, int n_samples, int n_importance) {
+static size_t render_seg_counters_offset(int R, int n_samples, int n_importance) {
     const size_t S = (size_t)n_samples + n_importance;
     const size_t bytes = render_cull_list_offset(R, n_samples, n_importance) + S * (size_t)R * 4;      // + the culled list (weight_cull > 0)
+    return (bytes + 255) / 256 * 256;
+}
+static size_t render_core_workspace_bytes(int R, int n_samples, int n_importance) {
+    const size_t bytes = render_seg_counters_offset(R, n_samples, n_importance) + 5 * ((size_t)R / 64 + 1) * 4;   // + per-segment counters of the five rounds (segment_rays > 0)
     return (bytes + 255) / 256 * 256;
 }
 // The occupied-point list is grouped by view-visibility signature only where that pays: the sort is 4 launches per 8 views and costs 0.1 - 0.25 ms
@@ -817,6 +859,13 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     hipStream_t s = (hipStream_t)stream;
     int rc;
     O2345_REQUIRE(io->sdf_mode == 0 || io->sdf_mode == 2, "render_rays: SDF mode %d (0 = fp32, 2 = split-f16; the bf16 mode 1 was removed)", io->sdf_mode);
+    // segment mode: the rays are consecutive render() calls of G rays each, evaluated together, the reference's two per-call rules applied per segment
+    const int G = io->segment_rays;
+    O2345_REQUIRE(G >= 0 && G % 64 == 0, "render_rays: segment_rays must be 0 or a multiple of 64 (got %d)", G);
+    O2345_REQUIRE(G == 0 || !io->near_ray, "render_rays: segment_rays needs one near / far pair (sample_dist is a per-call mean for per-ray near / far)");
+    const int n_seg = G ? (R + G - 1) / G : 0;
+    int* segc = (int*)((char*)workspace + render_seg_counters_offset(R, NS, NIMP));      // [5][n_seg]
+    if (G) O2345_HIP(hipMemsetAsync(segc, 0, (size_t)5 * n_seg * sizeof(int), s));
     auto sdf_eval = [&](int variant, const float* p, const int* idx, const int* cnt, long long n, float* out, float* grad) {
         if (io->sdf_mode == 2 && variant == 0) return o2345_sdf_mlp_x3(io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, stream);
         if (io->sdf_mode == 2 && variant == 2) return o2345_sdf_grad_x3(io->sdf_blob, io->vol_cl, io->D, p, idx, cnt, n, 0, 1.f, out, grad, stream);
@@ -835,6 +884,7 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     int cur = NS;
     for (int i = 0; i < 4; ++i) {
         ra.S = cur; ra.n_new = i ? (int)NI : 0; ra.inv_s = 64.f * (float)(1 << i); ra.count = count + i; ra.done = count + 8 + i;
+        ra.seg_rays = G; ra.n_seg = n_seg; ra.seg_cnt = G ? segc + (size_t)i * n_seg : nullptr; ra.seg_prev = (G && i) ? segc + (size_t)(i - 1) * n_seg : nullptr;
         if ((rc = ray_round_launch(RM_UPSAMPLE, ra, wbuf, stream))) return rc;             // incl. cat_z_vals' "more than one point" rule (round_epilogue)
         cur += ra.n_new;
         if ((rc = sdf_eval(0, pts, list, count + i, 0, new_sdf, nullptr))) return rc;
@@ -845,6 +895,7 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     float* fpts = pts;   // reuse
     // the last cat_z_vals fused with render_core's head
     ra.S = cur; ra.n_new = (int)NI; ra.count = count; ra.done = count + 8; ra.sample_dist = sample_dist;        // count was advanced by 4: slot 12
+    ra.seg_cnt = G ? segc + (size_t)4 * n_seg : nullptr; ra.seg_prev = G ? segc + (size_t)3 * n_seg : nullptr;
     ra.mid_z = io->mid_z; ra.dists = io->dists; ra.pts = fpts; ra.pm = io->pm; ra.o_sdf = io->sdf; ra.grad = io->grad; ra.rgb = io->rgb; ra.defaults_everywhere = 0;
     if ((rc = ray_round_launch(RM_FINALIZE, ra, nullptr, stream))) return rc;               // incl. render_core's "first 100 points" rule (round_epilogue)
     const bool cull = io->weight_cull > 0.f;
@@ -889,7 +940,8 @@ int o2345_render_rays(const O2345RenderIO* io, void* workspace, size_t workspace
     if (rc) return rc;
     if ((rc = o2345_ray_composite(io->rays_o, io->rays_d, R, (int)S, io->mid_z, io->dists, io->pm, io->sdf, io->grad, io->rgb, io->nviews, io->inv_s, io->alpha_inter_ratio, io->background,
                                   io->color, io->depth, io->weights, io->cdf, io->weights_sum, io->weights_max, io->depth_var, io->alpha_sum, io->grad_err, io->color_mask, stream))) return rc;
-    if (io->scalars) hipLaunchKernelGGL(k_ray_scalars, dim3(1), dim3(1024), 0, s, R, (int)S, io->alpha_sum, io->grad_err, count, io->scalars);
+    if (io->scalars) hipLaunchKernelGGL(k_ray_scalars, dim3(G ? n_seg : 1), dim3(1024), 0, s, R, (int)S, io->alpha_sum, io->grad_err, G ? segc + (size_t)4 * n_seg : count,
+                                        io->scalars, G);
     if (io->z_vals) O2345_HIP(hipMemcpyAsync(io->z_vals, z, S * RR * sizeof(float), hipMemcpyDeviceToDevice, s));
     return check_launch("render_rays");
 }

@@ -600,8 +600,12 @@ def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64,
              color_mask=torch.empty(R, dtype=torch.uint8, device=dev))
     if want_z:
         o["z_vals"] = f(S, R)
+    segment_rays = int(segment_rays)
+    if segment_rays < 0 or segment_rays % 64:
+        raise ValueError(f"render_rays: segment_rays must be 0 or a multiple of 64, got {segment_rays}")
+    n_seg = (R + segment_rays - 1) // segment_rays if segment_rays else 0
     if want_scalars:
-        o["scalars"] = f(4)
+        o["scalars"] = f(n_seg, 4) if segment_rays else f(4)
     io = _lib.RenderIO()
     for k in _SCENE_KEYS:
         setattr(io, k, scene[k].data_ptr())
