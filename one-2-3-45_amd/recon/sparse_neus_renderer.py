@@ -1,5 +1,7 @@
 """SparseNeuSRenderer + Projector on the HIP back end (mirror of models/sparse_neus_renderer.py:22-937 and
 models/projector.py:11-425; general rendering, lod 0)."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -80,6 +82,7 @@ class SparseNeuSRenderer(nn.Module):
         self.n_samples, self.n_importance, self.n_outside, self.perturb, self.alpha_type = n_samples, n_importance, n_outside, perturb, alpha_type
         self.rendering_projector = Projector()
         self.if_fitted_rendering = False
+        self._image, self._abandoned = None, 0         # whole-image mode (render())
 
     @torch.no_grad()
     def get_pts_mask_for_conditional_volume(self, pts, mask_volume):
@@ -113,6 +116,42 @@ class SparseNeuSRenderer(nn.Module):
         feat = feature_volume.reshape(C, -1).t()[idx]
         return torch.cat([torch.zeros(idx.numel(), 1, device=coords.device, dtype=coords.dtype), coords], dim=1), feat.contiguous()
 
+    # ---- the whole image behind the trainer's unchanged chunk loop ------------------------------------------------------------
+    # GenericTrainer.val_step renders an image as `for ro, rd in zip(rays_o.split(512), rays_d.split(512)): render(ro, rd, ...)` (trainer_generic.py:503-524):
+    # 128 calls of 16 launches each for a 256^2 image, every launch latency-bound.  The chunks are VIEWS of one ray tensor, so the first call can see the
+    # whole image: it renders EVERY 512-ray segment in one fused call (O2345RenderIO.segment_rays: the reference's two per-call rules and the per-call
+    # scalars per segment -- bit-identical to the separate calls, tests/test_gpu_segments.py), draws the host random numbers of every chunk in the
+    # reference's interleaved order (t_rand, pts_random, t_rand, ...), and the later calls return slices.  What a later call checks before it trusts the
+    # cache: the same ray tensors (object, storage, version), the same scene / network / scalar arguments, the expected position in the image, and that
+    # torch's host generator is exactly where the previous chunk left it (then it is advanced as the chunk's own draws would have).  Anything else falls
+    # back to a plain call.  O2345_WHOLE_IMAGE=0 disables the mode.
+    whole_image = os.environ.get("O2345_WHOLE_IMAGE", "1") not in ("", "0")
+    WHOLE_IMAGE_MAX_RAYS = 1 << 21
+
+    @staticmethod
+    def _chunk_of_image(t):
+        """t [n,3] that is a block of rows of a larger contiguous float32 tensor (`rays.reshape(-1, 3).split(chunk)`) -> (image [R,3] view of that tensor,
+        first row, that tensor) or None."""
+        b = t._base
+        if (b is None or t.dim() != 2 or t.shape[1] != 3 or t.dtype != torch.float32 or not t.is_contiguous() or b.dtype != torch.float32
+                or not b.is_contiguous() or b.numel() % 3 or not t.is_cuda):
+            return None
+        off = t.storage_offset() - b.storage_offset()
+        if off < 0 or off % 3 or off // 3 + t.shape[0] > b.numel() // 3:
+            return None
+        return b.view(-1, 3), off // 3, b
+
+    def _pack(self, o, sl, sc, sdf_random, var, inv_s, dev):
+        """The reference's returned dict (:609-633) for the rays ``sl`` of the call's sample-major outputs ``o``."""
+        return {"depth": o["depth"][sl, None], "color_fine": o["color"][sl], "color_fine_mask": o["color_mask"].view(torch.bool)[sl, None], "color_outside": None,
+                "color_outside_mask": None, "color_mlp": None, "color_mlp_mask": None,
+                "variance": _attr_cache(var, "_o2345_var_t", (str(dev),), lambda: torch.tensor(1.0 / inv_s, device=dev)),
+                "cdf_fine": o["cdf"][:, sl].t(), "depth_variance": o["depth_var"][sl, None], "weights_sum": o["weights_sum"][sl, None],
+                "weights_max": o["weights_max"][sl, None], "alpha_sum": sc[0], "alpha_mean": sc[1],
+                "gradients": o["grad"][:, sl].permute(1, 0, 2), "weights": o["weights"][:, sl].t(), "gradient_error_fine": sc[2],
+                "inside_sphere": o["pm"][:, sl].t(), "sdf": o["sdf"][:, sl].t().reshape(-1, 1), "sdf_random": sdf_random, "blended_color_patch": None,
+                "blended_color_patch_mask": None, "weights_sum_fg": o["weights_sum"][sl, None]}
+
     @torch.no_grad()
     def render(self, rays_o, rays_d, near, far, sdf_network, rendering_network, perturb_overwrite=-1, background_rgb=None,
                alpha_inter_ratio=0.0, lod=None, conditional_volume=None, conditional_valid_mask_volume=None, feature_maps=None,
@@ -126,10 +165,6 @@ class SparseNeuSRenderer(nn.Module):
         cm, proj, cam_pos = _scene_maps(feature_maps, color_maps, w2cs, intrinsics)
         R = rays_o.shape[0]
         dev = rays_o.device
-        # stratified jitter exactly as the reference draws it (:506-515): torch.rand(z_vals.shape) on the HOST generator, then moved to the device
-        # -> the same numbers as the reference under the same torch.manual_seed; drawn into pinned memory and copied asynchronously (torch's
-        # caching host allocator keeps the block until the copy has run), the kernel applies lower + (upper - lower) * t
-        t_rand = torch.rand(R, self.n_samples, pin_memory=dev.type == "cuda").to(dev, non_blocking=True) if perturb > 0 else None
         scene = dict(sdf_blob=sdf_network.sdf_layer.blob(), vol_cl=channel_last(conditional_volume),
                      maskvol=_attr_cache(conditional_valid_mask_volume, "_o2345_flat", (), lambda: conditional_valid_mask_volume.reshape(-1).contiguous().float()),
                      cmaps=cm, proj=proj, cam_pos=cam_pos, color_mfma_blob=rendering_network.mfma_blob(), color_x3_blob=rendering_network.x3_blob())
@@ -146,26 +181,76 @@ class SparseNeuSRenderer(nn.Module):
             if nr is None or fr is None:
                 raise ValueError(f"o2345 render: near / far must have 1 or N_rays = {R} elements (got {nt.numel()}, {ft.numel()})")
             sample_dist = float(((fr - nr) / self.n_samples).mean())                   # :484
+        air, bg = float(alpha_inter_ratio), 0.0 if background_rgb is None else float(background_rgb)        # None: nothing is added (:430-431)
+        qcam = _attr_cache(query_c2w, "_o2345_qcam", (), lambda: query_c2w.reshape(-1, 4, 4)[0, :3, 3].contiguous().float())
+        pin = dev.type == "cuda"
+        # ---- a chunk of an image the first chunk has already rendered (or is about to render) whole
+        img = None
+        if sample_dist is None and (self.whole_image or self._image is not None):
+            co, cd = self._chunk_of_image(rays_o), self._chunk_of_image(rays_d)
+            if co is not None and cd is not None and co[1] == cd[1] and co[0].shape == cd[0].shape and R < co[0].shape[0] <= self.WHOLE_IMAGE_MAX_RAYS:
+                ident = lambda t: (id(t), t.data_ptr(), t._version)
+                store = lambda t: (t.data_ptr(), t._version, t.numel())            # (the Python object of a view's base is not guaranteed to be the same one twice)
+                key = (store(co[2]), store(cd[2]), float(perturb) > 0, nr, fr, inv_s, air, bg, self.n_samples, self.n_importance, ident(conditional_volume),
+                       ident(conditional_valid_mask_volume), ident(feature_maps), ident(color_maps), ident(w2cs), ident(intrinsics), ident(query_c2w),
+                       id(scene["sdf_blob"]), id(scene["color_x3_blob"]), id(scene["color_mfma_blob"]))
+                img = (co[0], cd[0], co[1], key, (co[2], cd[2]))
+        c = self._image
+        if c is not None:
+            k = None
+            if img is not None and img[3] == c["key"] and img[2] % c["n"] == 0:
+                k = img[2] // c["n"]
+                if not (k == c["next"] and R == min(c["n"], c["R"] - img[2]) and torch.equal(torch.get_rng_state(), c["states"][k - 1])):
+                    k = None
+            if k is None:
+                self._image = None                           # another image, other arguments, out of order, or somebody drew from the host generator
+                if c["next"] <= 1:
+                    self._abandoned += 1                     # rendered whole, read once: after two such images in a row the mode switches itself off
+            else:
+                torch.set_rng_state(c["states"][k])          # the host generator advances as this chunk's own draws (t_rand, pts_random) would have
+                c["next"] = k + 1
+                self._abandoned = 0
+                if img[2] + R >= c["R"]:
+                    self._image = None                       # last chunk served: release the image's buffers
+                return self._pack(c["o"], slice(img[2], img[2] + R), c["o"]["scalars"][k], c["sdf_random"][k], var, inv_s, dev)
+        if img is not None and img[2] == 0 and self.whole_image and self._abandoned < 2 and R % 64 == 0:
+            io_, id_, _, key, bases = img
+            Ri = io_.shape[0]
+            K = (Ri + R - 1) // R
+            # the host stream of the K calls of the trainer's loop, in the reference's order: per call t_rand = torch.rand(z_vals.shape) (:506-515, only when
+            # perturb > 0), then pts_random = torch.rand([1024, 3]) (:606); the generator is then put back to where it stands after the FIRST call
+            t_all = torch.empty(Ri, self.n_samples, pin_memory=pin) if perturb > 0 else None
+            p_all = torch.empty(K, 1024, 3, pin_memory=pin)
+            states = []
+            for k in range(K):
+                a, b = k * R, min(Ri, (k + 1) * R)
+                if perturb > 0:
+                    t_all[a:b] = torch.rand(b - a, self.n_samples)
+                p_all[k] = torch.rand([1024, 3])
+                states.append(torch.get_rng_state())
+            torch.set_rng_state(states[0])
+            o = ops.render_rays(scene, io_, id_, nr, fr, self.n_samples, self.n_importance, inv_s, air, bg, qcam,
+                                t_rand=t_all.to(dev, non_blocking=True) if perturb > 0 else None, want_scalars=True, segment_rays=R)
+            pts_random = p_all.to(dev, non_blocking=True).view(-1, 3) * 2 - 1
+            sdf_random = ops.sdf_mlp(scene["sdf_blob"], scene["vol_cl"], pts_random, variant=0)["sdf"].view(K, 1024, 1)
+            # (scene / bases: the keyed blobs and ray storages stay alive while cached, so their addresses cannot be handed to other tensors)
+            self._image = dict(key=key, n=R, R=Ri, next=1, states=states, o=o, sdf_random=sdf_random, scene=scene, bases=bases)
+            return self._pack(o, slice(0, R), o["scalars"][0], sdf_random[0], var, inv_s, dev)
+        # ---- one plain call
+        # stratified jitter exactly as the reference draws it (:506-515): torch.rand(z_vals.shape) on the HOST generator, then moved to the device
+        # -> the same numbers as the reference under the same torch.manual_seed; drawn into pinned memory and copied asynchronously (torch's
+        # caching host allocator keeps the block until the copy has run), the kernel applies lower + (upper - lower) * t
+        t_rand = torch.rand(R, self.n_samples, pin_memory=pin).to(dev, non_blocking=True) if perturb > 0 else None
         o = ops.render_rays(scene, rays_o.contiguous().float(), rays_d.contiguous().float(), nr, fr, self.n_samples, self.n_importance,
-                            inv_s, float(alpha_inter_ratio), 0.0 if background_rgb is None else float(background_rgb),    # None: nothing is added (:430-431)
-                            _attr_cache(query_c2w, "_o2345_qcam", (), lambda: query_c2w.reshape(-1, 4, 4)[0, :3, 3].contiguous().float()),
-                            t_rand=t_rand, sample_dist=sample_dist, want_scalars=True)
-        S = self.n_samples + self.n_importance
+                            inv_s, air, bg, qcam, t_rand=t_rand, sample_dist=sample_dist, want_scalars=True)
         # the 1,024 random points of every call (:606): torch.rand([1024, 3]) on the HOST generator -- the second and last host draw of a call, after
         # t_rand -- moved to the device and mapped to (-1, 1) there, exactly the reference's expression: under one torch.manual_seed the host stream
         # advances by R * n_samples + 3,072 numbers per call, so every later chunk of an image draws the reference's jitter too.  Evaluated by the
         # SDF-only kernel (the reference's sdf() also returns 128 features nobody reads here)
-        pts_random = torch.rand([1024, 3], pin_memory=dev.type == "cuda").to(dev, non_blocking=True) * 2 - 1
+        pts_random = torch.rand([1024, 3], pin_memory=pin).to(dev, non_blocking=True) * 2 - 1
         sdf_random = ops.sdf_mlp(scene["sdf_blob"], scene["vol_cl"], pts_random, variant=0)["sdf"][:, None]
-        sc = o["scalars"]                            # [alpha_sum.mean(), alpha_sum.sum() / (R S), gradient error, evaluated points]: one tiny kernel inside the call
-        return {"depth": o["depth"][:, None], "color_fine": o["color"], "color_fine_mask": o["color_mask"].view(torch.bool)[:, None], "color_outside": None,
-                "color_outside_mask": None, "color_mlp": None, "color_mlp_mask": None,
-                "variance": _attr_cache(var, "_o2345_var_t", (str(dev),), lambda: torch.tensor(1.0 / inv_s, device=dev)),
-                "cdf_fine": o["cdf"].t(), "depth_variance": o["depth_var"][:, None], "weights_sum": o["weights_sum"][:, None],
-                "weights_max": o["weights_max"][:, None], "alpha_sum": sc[0], "alpha_mean": sc[1],
-                "gradients": o["grad"].permute(1, 0, 2), "weights": o["weights"].t(), "gradient_error_fine": sc[2],
-                "inside_sphere": o["pm"].t(), "sdf": o["sdf"].t().reshape(-1, 1), "sdf_random": sdf_random, "blended_color_patch": None,
-                "blended_color_patch_mask": None, "weights_sum_fg": o["weights_sum"][:, None]}
+        # scalars: [alpha_sum.mean(), alpha_sum.sum() / (R S), gradient error, evaluated points]: one tiny kernel inside the call
+        return self._pack(o, slice(0, R), o["scalars"], sdf_random, var, inv_s, dev)
 
     @torch.no_grad()
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, lod, sdf_network, rendering_network, background_alpha=None,
