@@ -71,6 +71,10 @@ class GeneralRenderingNetwork(nn.Module):
                 ps.append(lin["bias"])
         return ps
 
+    def weights_key(self):
+        """Identity of the current parameters (objects, storages, version counters): changes with any load / assignment / in-place update."""
+        return tuple((id(p), p.data_ptr(), p._version) for p in self._params())
+
     def _blobs(self):
         """(x3 blob, fp32-MFMA blob) of the current parameters; re-packed only when a parameter changed (object identity / data pointer / version counter)."""
         ps = self._params()

@@ -141,6 +141,48 @@ class SparseNeuSRenderer(nn.Module):
             return None
         return b.view(-1, 3), off // 3, b
 
+    def _pack_rows(self, c, a, b, k):
+        """The returned dict of chunk k = rays [a, b) of the cached image c."""
+        r, sc, var, dev, inv_s = c["rows"], c["o"]["scalars"][k], c["var"][0], c["dev"], c["inv_s"]
+        ws = r["weights_sum"][a:b]
+        return {"depth": r["depth"][a:b], "color_fine": r["color"][a:b], "color_fine_mask": r["mask"][a:b], "color_outside": None,
+                "color_outside_mask": None, "color_mlp": None, "color_mlp_mask": None,
+                "variance": _attr_cache(var, "_o2345_var_t", (str(dev),), lambda: torch.tensor(1.0 / inv_s, device=dev)),
+                "cdf_fine": r["cdf"][a:b], "depth_variance": r["depth_var"][a:b], "weights_sum": ws, "weights_max": r["weights_max"][a:b],
+                "alpha_sum": sc[0], "alpha_mean": sc[1], "gradients": r["grad"][a:b], "weights": r["weights"][a:b], "gradient_error_fine": sc[2],
+                "inside_sphere": r["pm"][a:b], "sdf": r["sdf"][a:b].reshape(-1, 1), "sdf_random": c["sdf_random"][k], "blended_color_patch": None,
+                "blended_color_patch_mask": None, "weights_sum_fg": ws}
+
+    def _serve_chunk(self, rays_o, rays_d, near, far, sdf_network, rendering_network, perturb, background_rgb, alpha_inter_ratio, args):
+        """-> the returned dict of this call if it is the NEXT chunk of the cached image under unchanged arguments, weights and host-generator state; else
+        None (the cache is dropped and the caller makes a plain call)."""
+        c = self._image
+        R = rays_o.shape[0]
+        co, cd = self._chunk_of_image(rays_o), self._chunk_of_image(rays_d)
+        store = lambda t: (t.data_ptr(), t._version, t.numel())
+        same = lambda t, rec: (t is rec[0] and getattr(t, "_version", None) == rec[1]) or (not torch.is_tensor(t) and not torch.is_tensor(rec[0]) and t == rec[0])
+        ok = (co is not None and cd is not None and co[1] == cd[1] and co[1] == c["next"] * c["n"] and R == min(c["n"], c["R"] - co[1])
+              and store(co[2]) == c["store"][0] and store(cd[2]) == c["store"][1] and (float(perturb) > 0) == c["perturb"]
+              and alpha_inter_ratio == c["air"] and background_rgb == c["bg"] and (self.n_samples, self.n_importance) == c["ns"]
+              and all(t is o and t._version == v for t, (o, v) in zip(args, c["args"])) and same(near, c["near"]) and same(far, c["far"])
+              and self.variance_network.variance is c["var"][0] and c["var"][0]._version == c["var"][1]
+              and sdf_network is c["nets"][0] and rendering_network is c["nets"][1]
+              and sdf_network.sdf_layer.weights_key() == c["wkeys"][0] and rendering_network.weights_key() == c["wkeys"][1]
+              and torch.equal(torch.get_rng_state(), c["states"][c["next"] - 1]))
+        if not ok:
+            self._image = None                               # another image, other arguments, out of order, or somebody drew from the host generator
+            if c["next"] <= 1:
+                self._abandoned += 1                         # rendered whole, read once: after two such images in a row the mode switches itself off
+            return None
+        k = c["next"]
+        torch.set_rng_state(c["states"][k])                  # the host generator advances as this chunk's own draws (t_rand, pts_random) would have
+        c["next"] = k + 1
+        self._abandoned = 0
+        a = co[1]
+        if a + R >= c["R"]:
+            self._image = None                               # last chunk served: release the image's buffers
+        return self._pack_rows(c, a, a + R, k)
+
     def _pack(self, o, sl, sc, sdf_random, var, inv_s, dev):
         """The reference's returned dict (:609-633) for the rays ``sl`` of the call's sample-major outputs ``o``."""
         return {"depth": o["depth"][sl, None], "color_fine": o["color"][sl], "color_fine_mask": o["color_mask"].view(torch.bool)[sl, None], "color_outside": None,
@@ -162,6 +204,11 @@ class SparseNeuSRenderer(nn.Module):
             raise NotImplementedError("o2345 render: general rendering without pre_sample / bg_ratio (the released val / export configuration)")
         if rays_o.shape[0] == 0:
             raise ValueError("o2345 render: empty ray batch")
+        if self._image is not None:                          # a later chunk of an image the first chunk rendered whole: a slice, after the checks of _serve_chunk
+            hit = self._serve_chunk(rays_o, rays_d, near, far, sdf_network, rendering_network, perturb, background_rgb, alpha_inter_ratio,
+                                    (conditional_volume, conditional_valid_mask_volume, feature_maps, color_maps, w2cs, intrinsics, query_c2w))
+            if hit is not None:
+                return hit
         cm, proj, cam_pos = _scene_maps(feature_maps, color_maps, w2cs, intrinsics)
         R = rays_o.shape[0]
         dev = rays_o.device
@@ -184,37 +231,14 @@ class SparseNeuSRenderer(nn.Module):
         air, bg = float(alpha_inter_ratio), 0.0 if background_rgb is None else float(background_rgb)        # None: nothing is added (:430-431)
         qcam = _attr_cache(query_c2w, "_o2345_qcam", (), lambda: query_c2w.reshape(-1, 4, 4)[0, :3, 3].contiguous().float())
         pin = dev.type == "cuda"
-        # ---- a chunk of an image the first chunk has already rendered (or is about to render) whole
+        # ---- the FIRST chunk of an image: render every segment now (later chunks: _serve_chunk above)
         img = None
-        if sample_dist is None and (self.whole_image or self._image is not None):
+        if sample_dist is None and self.whole_image and self._abandoned < 2 and R % 64 == 0:
             co, cd = self._chunk_of_image(rays_o), self._chunk_of_image(rays_d)
-            if co is not None and cd is not None and co[1] == cd[1] and co[0].shape == cd[0].shape and R < co[0].shape[0] <= self.WHOLE_IMAGE_MAX_RAYS:
-                ident = lambda t: (id(t), t.data_ptr(), t._version)
-                store = lambda t: (t.data_ptr(), t._version, t.numel())            # (the Python object of a view's base is not guaranteed to be the same one twice)
-                key = (store(co[2]), store(cd[2]), float(perturb) > 0, nr, fr, inv_s, air, bg, self.n_samples, self.n_importance, ident(conditional_volume),
-                       ident(conditional_valid_mask_volume), ident(feature_maps), ident(color_maps), ident(w2cs), ident(intrinsics), ident(query_c2w),
-                       id(scene["sdf_blob"]), id(scene["color_x3_blob"]), id(scene["color_mfma_blob"]))
-                img = (co[0], cd[0], co[1], key, (co[2], cd[2]))
-        c = self._image
-        if c is not None:
-            k = None
-            if img is not None and img[3] == c["key"] and img[2] % c["n"] == 0:
-                k = img[2] // c["n"]
-                if not (k == c["next"] and R == min(c["n"], c["R"] - img[2]) and torch.equal(torch.get_rng_state(), c["states"][k - 1])):
-                    k = None
-            if k is None:
-                self._image = None                           # another image, other arguments, out of order, or somebody drew from the host generator
-                if c["next"] <= 1:
-                    self._abandoned += 1                     # rendered whole, read once: after two such images in a row the mode switches itself off
-            else:
-                torch.set_rng_state(c["states"][k])          # the host generator advances as this chunk's own draws (t_rand, pts_random) would have
-                c["next"] = k + 1
-                self._abandoned = 0
-                if img[2] + R >= c["R"]:
-                    self._image = None                       # last chunk served: release the image's buffers
-                return self._pack(c["o"], slice(img[2], img[2] + R), c["o"]["scalars"][k], c["sdf_random"][k], var, inv_s, dev)
-        if img is not None and img[2] == 0 and self.whole_image and self._abandoned < 2 and R % 64 == 0:
-            io_, id_, _, key, bases = img
+            if (co is not None and cd is not None and co[1] == cd[1] == 0 and co[0].shape == cd[0].shape and R < co[0].shape[0] <= self.WHOLE_IMAGE_MAX_RAYS):
+                img = (co[0], cd[0], (co[2], cd[2]))
+        if img is not None:
+            io_, id_, bases = img
             Ri = io_.shape[0]
             K = (Ri + R - 1) // R
             # the host stream of the K calls of the trainer's loop, in the reference's order: per call t_rand = torch.rand(z_vals.shape) (:506-515, only when
@@ -234,8 +258,17 @@ class SparseNeuSRenderer(nn.Module):
             pts_random = p_all.to(dev, non_blocking=True).view(-1, 3) * 2 - 1
             sdf_random = ops.sdf_mlp(scene["sdf_blob"], scene["vol_cl"], pts_random, variant=0)["sdf"].view(K, 1024, 1)
             # (scene / bases: the keyed blobs and ray storages stay alive while cached, so their addresses cannot be handed to other tensors)
-            self._image = dict(key=key, n=R, R=Ri, next=1, states=states, o=o, sdf_random=sdf_random, scene=scene, bases=bases)
-            return self._pack(o, slice(0, R), o["scalars"][0], sdf_random[0], var, inv_s, dev)
+            store = lambda t: (t.data_ptr(), t._version, t.numel())     # (the Python object of a view's base is not guaranteed to be the same one twice)
+            args = (conditional_volume, conditional_valid_mask_volume, feature_maps, color_maps, w2cs, intrinsics, query_c2w)
+            rows = dict(depth=o["depth"][:, None], color=o["color"], mask=o["color_mask"].view(torch.bool)[:, None], cdf=o["cdf"].t(), depth_var=o["depth_var"][:, None],
+                        weights_sum=o["weights_sum"][:, None], weights_max=o["weights_max"][:, None], grad=o["grad"].permute(1, 0, 2), weights=o["weights"].t(),
+                        pm=o["pm"].t(), sdf=o["sdf"].t())                   # ray-major views of the whole image: a chunk is a row range of each
+            self._image = dict(n=R, R=Ri, next=1, states=states, o=o, rows=rows, sdf_random=sdf_random, scene=scene, bases=bases, store=(store(bases[0]), store(bases[1])),
+                               args=[(t, t._version) for t in args], near=(near, getattr(near, "_version", None)), far=(far, getattr(far, "_version", None)),
+                               perturb=float(perturb) > 0, air=alpha_inter_ratio, bg=background_rgb, var=(var, var._version), inv_s=inv_s,
+                               wkeys=(sdf_network.sdf_layer.weights_key(), rendering_network.weights_key()), nets=(sdf_network, rendering_network),
+                               ns=(self.n_samples, self.n_importance), dev=dev)
+            return self._pack_rows(self._image, 0, R, 0)
         # ---- one plain call
         # stratified jitter exactly as the reference draws it (:506-515): torch.rand(z_vals.shape) on the HOST generator, then moved to the device
         # -> the same numbers as the reference under the same torch.manual_seed; drawn into pinned memory and copied asynchronously (torch's

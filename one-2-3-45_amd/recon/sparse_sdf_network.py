@@ -80,6 +80,10 @@ class LatentSDFLayer(nn.Module):
         """The parameters in a fixed order without walking the module tree (named_parameters() costs 0.2 ms, and render() asks per 512-ray chunk)."""
         return [m._parameters[n] for m in (self.lin0, self.lin1, self.lin2) for n in ("bias", "weight_g", "weight_v")]
 
+    def weights_key(self):
+        """Identity of the current parameters (objects, storages, version counters): changes with any load / assignment / in-place update."""
+        return tuple((id(p), p.data_ptr(), p._version) for p in self._params())
+
     def blob(self):
         ps = self._params()
         key = tuple((id(p), p.data_ptr(), p._version) for p in ps)
