@@ -1,5 +1,6 @@
 """SparseNeuSRenderer + Projector on the HIP back end (mirror of models/sparse_neus_renderer.py:22-937 and
 models/projector.py:11-425; general rendering, lod 0)."""
+import contextlib
 import os
 
 import numpy as np
@@ -82,7 +83,7 @@ class SparseNeuSRenderer(nn.Module):
         self.n_samples, self.n_importance, self.n_outside, self.perturb, self.alpha_type = n_samples, n_importance, n_outside, perturb, alpha_type
         self.rendering_projector = Projector()
         self.if_fitted_rendering = False
-        self._image, self._abandoned = None, 0         # whole-image mode (render())
+        self._image, self._abandoned, self._side = None, 0, None         # whole-image mode (render())
 
     @torch.no_grad()
     def get_pts_mask_for_conditional_volume(self, pts, mask_volume):
@@ -143,14 +144,23 @@ class SparseNeuSRenderer(nn.Module):
 
     def _pack_rows(self, c, a, b, k):
         """The returned dict of chunk k = rays [a, b) of the cached image c."""
-        r, sc, var, dev, inv_s = c["rows"], c["o"]["scalars"][k], c["var"][0], c["dev"], c["inv_s"]
+        bt = c["batches"][k // c["KB"]]
+        if not bt["joined"]:                       # first chunk of a batch rendered on the side stream: the caller's stream waits for THAT batch only, and the
+            bt["joined"] = True                    # caching allocator learns that the batch's buffers are used on the caller's stream too
+            if bt["event"] is not None:
+                cur = torch.cuda.current_stream(c["dev"])
+                cur.wait_event(bt["event"])
+                for t in list(bt["o"].values()) + [bt["sdf_random"]]:
+                    t.record_stream(cur)
+        a, b, k = a - bt["a0"], b - bt["a0"], k - bt["k0"]
+        r, sc, var, dev, inv_s = bt["rows"], bt["o"]["scalars"][k], c["var"][0], c["dev"], c["inv_s"]
         ws = r["weights_sum"][a:b]
         return {"depth": r["depth"][a:b], "color_fine": r["color"][a:b], "color_fine_mask": r["mask"][a:b], "color_outside": None,
                 "color_outside_mask": None, "color_mlp": None, "color_mlp_mask": None,
                 "variance": _attr_cache(var, "_o2345_var_t", (str(dev),), lambda: torch.tensor(1.0 / inv_s, device=dev)),
                 "cdf_fine": r["cdf"][a:b], "depth_variance": r["depth_var"][a:b], "weights_sum": ws, "weights_max": r["weights_max"][a:b],
                 "alpha_sum": sc[0], "alpha_mean": sc[1], "gradients": r["grad"][a:b], "weights": r["weights"][a:b], "gradient_error_fine": sc[2],
-                "inside_sphere": r["pm"][a:b], "sdf": r["sdf"][a:b].reshape(-1, 1), "sdf_random": c["sdf_random"][k], "blended_color_patch": None,
+                "inside_sphere": r["pm"][a:b], "sdf": r["sdf"][a:b].reshape(-1, 1), "sdf_random": bt["sdf_random"][k], "blended_color_patch": None,
                 "blended_color_patch_mask": None, "weights_sum_fg": ws}
 
     def _serve_chunk(self, rays_o, rays_d, near, far, sdf_network, rendering_network, perturb, background_rgb, alpha_inter_ratio, args):
@@ -241,29 +251,48 @@ class SparseNeuSRenderer(nn.Module):
             io_, id_, bases = img
             Ri = io_.shape[0]
             K = (Ri + R - 1) // R
+            # An image of >= 16,384 rays goes out in four batches of whole segments on a SIDE stream: the host draws a batch's random numbers, launches it,
+            # draws the next -- and later, while the trainer pulls chunk after chunk to the host (a .cpu() per chunk on ITS stream), the GPU is still rendering
+            # the following batches.  A chunk waits only for its own batch (one event per batch), not for the image.
+            nb = 4 if (Ri >= 16384 and dev.type == "cuda") else 1
+            KB = (K + nb - 1) // nb
+            cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+            if nb > 1:
+                if self._side is None or self._side.device != dev:
+                    self._side = torch.cuda.Stream(device=dev)
+                self._side.wait_stream(cur)                                     # the scene's tensors were produced on the caller's stream
             # the host stream of the K calls of the trainer's loop, in the reference's order: per call t_rand = torch.rand(z_vals.shape) (:506-515, only when
             # perturb > 0), then pts_random = torch.rand([1024, 3]) (:606); the generator is then put back to where it stands after the FIRST call
-            t_all = torch.empty(Ri, self.n_samples, pin_memory=pin) if perturb > 0 else None
-            p_all = torch.empty(K, 1024, 3, pin_memory=pin)
-            states = []
-            for k in range(K):
-                a, b = k * R, min(Ri, (k + 1) * R)
-                if perturb > 0:
-                    t_all[a:b] = torch.rand(b - a, self.n_samples)
-                p_all[k] = torch.rand([1024, 3])
-                states.append(torch.get_rng_state())
+            states, batches = [], []
+            for bi in range(0, K, KB):
+                k1 = min(K, bi + KB)
+                a0, a1 = bi * R, min(Ri, k1 * R)
+                t_b = torch.empty(a1 - a0, self.n_samples, pin_memory=pin) if perturb > 0 else None
+                p_b = torch.empty(k1 - bi, 1024, 3, pin_memory=pin)
+                for k in range(bi, k1):
+                    ra, rb = k * R - a0, min(Ri, (k + 1) * R) - a0
+                    if perturb > 0:
+                        t_b[ra:rb] = torch.rand(rb - ra, self.n_samples)
+                    p_b[k - bi] = torch.rand([1024, 3])
+                    states.append(torch.get_rng_state())
+                with (torch.cuda.stream(self._side) if nb > 1 else contextlib.nullcontext()):
+                    o = ops.render_rays(scene, io_[a0:a1], id_[a0:a1], nr, fr, self.n_samples, self.n_importance, inv_s, air, bg, qcam,
+                                        t_rand=t_b.to(dev, non_blocking=True) if perturb > 0 else None, want_scalars=True, segment_rays=R)
+                    pts_random = p_b.to(dev, non_blocking=True).view(-1, 3) * 2 - 1
+                    sdf_random = ops.sdf_mlp(scene["sdf_blob"], scene["vol_cl"], pts_random, variant=0)["sdf"].view(k1 - bi, 1024, 1)
+                    rows = dict(depth=o["depth"][:, None], color=o["color"], mask=o["color_mask"].view(torch.bool)[:, None], cdf=o["cdf"].t(),
+                                depth_var=o["depth_var"][:, None], weights_sum=o["weights_sum"][:, None], weights_max=o["weights_max"][:, None],
+                                grad=o["grad"].permute(1, 0, 2), weights=o["weights"].t(), pm=o["pm"].t(), sdf=o["sdf"].t())      # ray-major views: a chunk is a row range
+                    ev = None
+                    if nb > 1:
+                        ev = torch.cuda.Event()
+                        ev.record(self._side)
+                batches.append(dict(a0=a0, k0=bi, o=o, rows=rows, sdf_random=sdf_random, event=ev, joined=False))
             torch.set_rng_state(states[0])
-            o = ops.render_rays(scene, io_, id_, nr, fr, self.n_samples, self.n_importance, inv_s, air, bg, qcam,
-                                t_rand=t_all.to(dev, non_blocking=True) if perturb > 0 else None, want_scalars=True, segment_rays=R)
-            pts_random = p_all.to(dev, non_blocking=True).view(-1, 3) * 2 - 1
-            sdf_random = ops.sdf_mlp(scene["sdf_blob"], scene["vol_cl"], pts_random, variant=0)["sdf"].view(K, 1024, 1)
-            # (scene / bases: the keyed blobs and ray storages stay alive while cached, so their addresses cannot be handed to other tensors)
             store = lambda t: (t.data_ptr(), t._version, t.numel())     # (the Python object of a view's base is not guaranteed to be the same one twice)
             args = (conditional_volume, conditional_valid_mask_volume, feature_maps, color_maps, w2cs, intrinsics, query_c2w)
-            rows = dict(depth=o["depth"][:, None], color=o["color"], mask=o["color_mask"].view(torch.bool)[:, None], cdf=o["cdf"].t(), depth_var=o["depth_var"][:, None],
-                        weights_sum=o["weights_sum"][:, None], weights_max=o["weights_max"][:, None], grad=o["grad"].permute(1, 0, 2), weights=o["weights"].t(),
-                        pm=o["pm"].t(), sdf=o["sdf"].t())                   # ray-major views of the whole image: a chunk is a row range of each
-            self._image = dict(n=R, R=Ri, next=1, states=states, o=o, rows=rows, sdf_random=sdf_random, scene=scene, bases=bases, store=(store(bases[0]), store(bases[1])),
+            # (scene / bases: the packed weights and ray storages stay alive while cached, so their addresses cannot be handed to other tensors)
+            self._image = dict(n=R, R=Ri, KB=KB, next=1, states=states, batches=batches, scene=scene, bases=bases, store=(store(bases[0]), store(bases[1])),
                                args=[(t, t._version) for t in args], near=(near, getattr(near, "_version", None)), far=(far, getattr(far, "_version", None)),
                                perturb=float(perturb) > 0, air=alpha_inter_ratio, bg=background_rgb, var=(var, var._version), inv_s=inv_s,
                                wkeys=(sdf_network.sdf_layer.weights_key(), rendering_network.weights_key()), nets=(sdf_network, rendering_network),

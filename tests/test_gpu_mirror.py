@@ -162,20 +162,23 @@ def test_two_consecutive_chunks_draw_the_references_host_stream(S, monkeypatch):
     assert not np.array_equal(gp["c0_t_rand"], gp["c1_t_rand"])
 
 
-def test_whole_image_behind_the_chunk_loop_equals_the_per_chunk_calls(S):
+@pytest.mark.parametrize("scale", [1, 4])
+def test_whole_image_behind_the_chunk_loop_equals_the_per_chunk_calls(S, scale):
     """the trainer's loop `for ro, rd in zip(rays_o.split(512), rays_d.split(512)): render(ro, rd, ...)` (trainer_generic.py:503-524) on the
     40 x 40 query image (4 chunks, the last one 64 rays).  With the whole-image mode the FIRST call renders every segment in one fused call and the later
     calls are slices; every one of the 23 returned entries of every chunk must be bit-identical to the plain per-chunk calls -- deterministic and with the
     default perturb = 1 under one torch.manual_seed --, the host generator must end where the reference's would, and the golden of the reference's own first
-    two chunks (ref_perturb2.npz) must be met through the views as well.  Also: a call that does not continue the image (other arguments, out of order, a
-    foreign draw from the host generator) falls back to a plain call."""
+    two chunks (ref_perturb2.npz) must be met through the views as well.  scale = 4: a 160 x 160 image of the same camera (25,600 rays, 50 chunks) -- from
+    16,384 rays on the image is rendered in four batches on a side stream and a chunk waits for its own batch only.  Also: a call that does not continue
+    the image (other arguments, out of order, a foreign draw from the host generator) falls back to a plain call."""
     import os
     pkg = importlib.import_module("one-2-3-45_amd")
     gp = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_perturb2.npz"))
     g, G, T = S["G"]["g"], S["G"], S["T"]
     sc, HW = G["sc"], G["cfg"]["HW"]
-    ro, rd = pkg.synth.gen_rays(sc["query_intrinsic"], sc["query_c2w"], HW, HW)
+    ro, rd = pkg.synth.gen_rays(sc["query_intrinsic"], sc["query_c2w"], HW, HW, scale=scale)
     ro, rd = T(ro)[None], T(rd)[None]                                  # [1, HW, 3] like sample['rays']['rays_o']
+    n_chunks = (ro.shape[1] + 511) // 512
     dense, mask = T(g["dense"])[None], T(g["mask"])[None, None]
     kw = dict(background_rgb=1.0, alpha_inter_ratio=1.0, lod=0, conditional_volume=dense, conditional_valid_mask_volume=mask, feature_maps=T(G["fmaps"]),
               color_maps=T(sc["images"]), w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW], query_c2w=T(sc["query_c2w"])[None],
@@ -196,7 +199,7 @@ def test_whole_image_behind_the_chunk_loop_equals_the_per_chunk_calls(S):
             fused, st_fused = loop(perturb, 4321)
             assert ren._image is None, "the last chunk releases the image"
             assert torch.equal(st_plain, st_fused), "host generator state after the image"
-            assert len(plain) == len(fused) == 4 and plain[3]["depth"].shape[0] == 64
+            assert len(plain) == len(fused) == n_chunks and (scale != 1 or plain[3]["depth"].shape[0] == 64)
             for k, (a, b) in enumerate(zip(plain, fused)):
                 assert set(a) == set(b) and len(a) == 23
                 for key in a:
@@ -204,7 +207,7 @@ def test_whole_image_behind_the_chunk_loop_equals_the_per_chunk_calls(S):
                         assert b[key] is None, key
                     else:
                         assert a[key].shape == b[key].shape and torch.equal(a[key], b[key]), (perturb, k, key)
-            if perturb < 0:                                          # the reference's own first two chunks under the same seed
+            if perturb < 0 and scale == 1:                           # the reference's own first two chunks under the same seed
                 for c in range(2):
                     assert rel(fused[c]["sdf_random"], gp[f"c{c}_sdf_random"]) < 2e-5
                     for key in ("color_fine", "depth", "weights_sum"):
