@@ -20,7 +20,9 @@ N > 1: one process per GPU, every rank reconstructs its own scenes: embarrassing
 Besides the contract's line (config 2), rank 0 attaches: `parity_fullsize` (the cpu_baseline rays compared with the HIP outputs),
 `c3` (BASELINE config 3: 32 distinct scenes dealt over the ranks, inputs uploaded host->device inside the step), `ref_config`
 (the reference's own V=32 / 96^3 / 256^3 configuration), `config5` (256^3 volume, 1024^2 rays, 512^3 grid), `fp32_whole_step_ms`,
-`cpu_baseline_reference` (the reference's own modules timed in the build container).  `--quick` skips them.
+`cpu_baseline_reference` (the reference's own modules timed on a GPU box's host cores: tools/reference_cpu_on_gpu_box.sh), `parity_reference` (HIP vs the
+reference's own outputs at BASELINE config 2 / 1: tests/golden/ref_c2_sample.npz, ref_c1.npz), `trained_regime` (a trained model's variance: what the
+weight-bounded colour work removal buys).  `--quick` skips them.
 """
 import argparse
 import importlib
@@ -177,15 +179,28 @@ def trained_regime_block(dev, wt, inp, D):
     try:
         for v in (0.2, 0.45, 0.65):
             wt.variance, wt.inv_s = v, float(np.clip(np.exp(10.0 * v), 1e-6, 1e6))
-            fn = lambda: pipeline.render(wt, vol, inp["proj"], inp["cam_pos"], inp["rays_o"], inp["rays_d"], inp["near"], inp["far"], inp["qcam"])
-            o = fn()
+            scene = dict(sdf_blob=wt.sdf_blob, vol_cl=vol["vol_cl"], maskvol=vol["maskvol"], cmaps=vol["cmaps"], proj=inp["proj"], cam_pos=inp["cam_pos"],
+                         color_mfma_blob=wt.color_mblob, color_x3_blob=wt.color_xblob, sdf_precision=wt.sdf_precision, color_precision=wt.color_precision)
+            call = lambda cull, stats=None: ops.render_rays(scene, inp["rays_o"], inp["rays_d"], inp["near"], inp["far"], 64, 64, wt.inv_s, 1.0, 1.0, inp["qcam"],
+                                                            weight_cull=cull, color_stats=stats)
+            fn = lambda: call(None)                    # the default: config.WEIGHT_CULL
+            sa, sb = ops.color_stats_buffer(dev), ops.color_stats_buffer(dev)
+            o_full = call(0.0, sa)
+            o = call(None, sb)
+            pa, pb = ops.color_stats_read(sa)["pairs_network"], ops.color_stats_read(sb)["pairs_network"]
+            dcol = float((o["color"] - o_full["color"]).abs().max())
+            same = all(bool(torch.equal(o[k], o_full[k])) for k in ("depth", "weights", "weights_sum", "color_mask", "sdf", "grad", "nviews"))
+            o_full = None
             occ = o["pm"] > 0
             w = o["weights"][occ]
             n = int(w.numel())
             fr = lambda t: float((w < t).sum()) / max(1, n)
             out[f"variance_{v}"] = {"inv_s": wt.inv_s, "occupied_samples": n, "rays_hitting_surface": int((o["weights_sum"] > 0.5).sum()),
                                     "frac_occupied_with_weight_below": {"2^-24": fr(2.0 ** -24), "1e-6": fr(1e-6), "1e-5": fr(1e-5), "1e-4": fr(1e-4), "1e-3": fr(1e-3)},
-                                    "render_ms_median": median_ms(fn, reps=3)}
+                                    "render_ms_median": median_ms(fn, reps=3), "render_ms_median_exhaustive": median_ms(lambda: call(0.0), reps=3),
+                                    "weight_cull": config.weight_cull(), "colour_tile_view_pairs_exhaustive_vs_culled": [pa, pb],
+                                    "colour_max_abs_difference_vs_exhaustive": dcol, "bound": 128 * config.weight_cull(),
+                                    "everything_but_colour_bit_identical": same}
             o = w = occ = None
     finally:
         wt.variance, wt.inv_s = old
@@ -538,13 +553,14 @@ def dropin_block(dev):
     import dropin_bench as DB
     out = {"warm": DB.run(dev, reps=5)}
     keep = ("import_torch_ms", "hip_context_ms", "load_library_ms", "construct_networks_ms", "export_mesh_first_call_ms", "export_mesh_first_call_stages_ms",
-            "val_step_first_call_ms", "export_mesh_warm_ms_median", "val_step_warm_ms_median", "process_total_s", "cpu_threads", "vertices", "error", "rc")
+            "val_step_first_call_ms", "export_mesh_warm_ms_median", "val_step_warm_ms_median", "val_step_warm_ms_median_per_chunk_calls", "process_total_s", "cpu_threads", "vertices", "error", "rc")
     for name in ("fresh_process_1", "fresh_process_2"):
         d = DB.cold_subprocess()
         out[name] = {k: d[k] for k in keep if k in d}
     w = out["warm"]
     out["summary"] = {"export_mesh_warm_ms": w["export_mesh_warm_ms_median"], "export_mesh_fresh_process_ms": out["fresh_process_2"].get("export_mesh_first_call_ms"),
-                      "val_step_warm_ms": w.get("val_step_warm_ms_median"), "val_step_with_validate_mesh_360_warm_ms": w.get("val_step_with_validate_mesh_360_ms"),
+                      "val_step_warm_ms": w.get("val_step_warm_ms_median"), "val_step_warm_ms_per_chunk_calls": w.get("val_step_warm_ms_median_per_chunk_calls"),
+                      "val_step_with_validate_mesh_360_warm_ms": w.get("val_step_with_validate_mesh_360_ms"),
                       "reference_published_export_mesh_ms": 2488.7,
                       "speedup_vs_published_fresh_process": (2488.7 / out["fresh_process_2"]["export_mesh_first_call_ms"]) if out["fresh_process_2"].get("export_mesh_first_call_ms") else None}
     return out
@@ -689,7 +705,8 @@ def main():
                                    f"{a.views} views 256x256, {a.vol}^3 volume, "
                                    f"{n_rays} rays (64+64 samples), mesh grid {a.mesh_res}^3; whole scene pass per step",
                        "views": a.views, "volume": a.vol, "rays": n_rays, "mesh_res": a.mesh_res, "parallelism": f"scenes x{world}",
-                       "precision": a.precision},
+                       "precision": a.precision, "variance": wt.variance, "inv_s": wt.inv_s, "weight_cull": config.weight_cull(),
+                       "weights": "checkpoint" if a.ckpt else "seeded stand-ins (untrained: variance 0.2 -> inv_s 7.4; the trained regime is the `trained_regime` block)"},
             "render_rays_per_s": n_rays / (tm.mean("render") * 1e-3), "mesh_extract_ms": tm.mean("mesh"),
             "volume_build_ms": tm.mean("volume"), "render_ms": tm.mean("render"),
             "mesh": {"vertices": int(mesh[0].shape[0]), "triangles": int(mesh[1].shape[0])}, "kept_voxels": n_vox,

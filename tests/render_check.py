@@ -147,8 +147,12 @@ def three_clause(ops, dev, scene, a, ro, rd, near, far, variance=0.2, air=1.0, b
           f"their sample lists differ by {[round(float(x), 7) for x in zerr[dev_rays][:8]]}", file=sys.stderr)
     assert not strict_e2e or bool((zerr[dev_rays] > 1e-6).all()), (label, "a deviating ray has coinciding sample lists")
     # Hard regression caps on the END-TO-END error, independent of the sensitivity argument above (a sampler regression that changes many sample lists
-    # must not hide inside "4 x the oracle's own sensitivity").  Measured at BASELINE config 2 on the driver's 4,320 rays (BENCH_r03 parity_fullsize):
-    # colour max 4.2e-2, q99 3.1e-3, 2.2 % of the rays above 1e-3, 9.1 % above 1e-4.
+    # must not hide inside "4 x the oracle's own sensitivity").  This comparison runs oracle and HIP on the SAME latent volume (HIP's), so only SDF-evaluation
+    # differences (1e-6 class) enter: measured at BASELINE config 2 on the driver's 4,320 rays colour max 4.2e-2, q99 3.1e-3, 2.2 % of the rays above 1e-3.
+    # Where the caps stand against the REFERENCE (round 5, tests/golden/ref_c2_sample.npz, make_golden_scale.SELFSENS_*): the reference's own render() against
+    # itself on a volume perturbed by 1e-6 x max gives colour max 7.8e-2, q99 1.4e-2, 7.2 % of the rays above 1e-3 at config 2 -- the caps below are TIGHTER than
+    # what the reference does to itself under a smaller perturbation than any second implementation of its volume build has.  The comparison from the images
+    # (volumes differ by 1.6e-6 rms) is tests/test_gpu_refscale.py::test_render_end_to_end_vs_reference, bounded by the same reference-vs-reference numbers.
     res["e2e"]["frac_color_gt_1e-3"] = float((cerr > 1e-3).float().mean())
     res["e2e"]["frac_rays_with_other_lists_and_color_gt_bound"] = float(len(dev_rays)) / R
     if e2e_caps is None:

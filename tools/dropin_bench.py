@@ -289,6 +289,16 @@ def _run(dev, reps, resolution, cold, val, out_dir):
         tr.val_step(sample, st=st)
         res["val_step_warm_stages_ms"] = st.ms()
         res["val_rays_per_s_chunked"] = 65536 / (res["val_step_warm_ms_median"] * 1e-3)
+        # A/B: the same loop with the whole-image mode off (O2345_WHOLE_IMAGE=0): every 512-ray chunk is its own render call of 16 launches (round 4's path)
+        tr.sdf_renderer_lod0.whole_image = False
+        try:
+            tr.val_step(sample)
+            ts = _bracket(lambda: tr.val_step(sample), reps)
+        finally:
+            tr.sdf_renderer_lod0.whole_image = True
+        res["val_step_warm_ms_median_per_chunk_calls"] = float(np.median(ts))
+        res["val_step_note"] = ("the trainer's unchanged loop over 128 chunks of 512 rays (trainer_generic.py:503-524); whole-image mode: the first render() call "
+                                "renders every chunk in four fused segmented calls on a side stream, the other 127 calls return slices")
         # what the runner's "val_step time" additionally contains: validate_mesh at its default resolution of 360 (trainer_generic.py:1271, :598-606)
         tr.val_step(sample, mesh_resolution=360)
         st = Stages(True)
