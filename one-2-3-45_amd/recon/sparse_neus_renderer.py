@@ -128,6 +128,7 @@ class SparseNeuSRenderer(nn.Module):
     # back to a plain call.  O2345_WHOLE_IMAGE=0 disables the mode.
     whole_image = os.environ.get("O2345_WHOLE_IMAGE", "1") not in ("", "0")
     WHOLE_IMAGE_MAX_RAYS = 1 << 21
+    image_batches = int(os.environ.get("O2345_IMAGE_BATCHES", "4"))
 
     @staticmethod
     def _chunk_of_image(t):
@@ -251,10 +252,10 @@ class SparseNeuSRenderer(nn.Module):
             io_, id_, bases = img
             Ri = io_.shape[0]
             K = (Ri + R - 1) // R
-            # An image of >= 16,384 rays goes out in four batches of whole segments on a SIDE stream: the host draws a batch's random numbers, launches it,
+            # An image of >= 8,192 rays goes out in up to `image_batches` batches of whole segments on a SIDE stream: the host draws a batch's random numbers, launches it,
             # draws the next -- and later, while the trainer pulls chunk after chunk to the host (a .cpu() per chunk on ITS stream), the GPU is still rendering
             # the following batches.  A chunk waits only for its own batch (one event per batch), not for the image.
-            nb = 4 if (Ri >= 16384 and dev.type == "cuda") else 1
+            nb = max(1, min(self.image_batches, Ri // 4096)) if dev.type == "cuda" else 1          # (a batch of >= 4,096 rays runs the streaming sampler kernels)
             KB = (K + nb - 1) // nb
             cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
             if nb > 1:
