@@ -136,7 +136,7 @@ class SparseNeuSRenderer(nn.Module):
         first row, that tensor) or None."""
         b = t._base
         if (b is None or t.dim() != 2 or t.shape[1] != 3 or t.dtype != torch.float32 or not t.is_contiguous() or b.dtype != torch.float32
-                or not b.is_contiguous() or b.numel() % 3 or not t.is_cuda):
+                or not b.is_contiguous() or b.numel() % 3):
             return None
         off = t.storage_offset() - b.storage_offset()
         if off < 0 or off % 3 or off // 3 + t.shape[0] > b.numel() // 3:

@@ -266,7 +266,19 @@ def color_from_features(blob, geometry_feat, rgb_feat, ray_diff, mask, x3=True, 
 
 
 def render_rays(scene, rays_o, rays_d, near, far, n_samples=64, n_importance=64, inv_s=None, alpha_inter_ratio=1.0, background=1.0,
-                query_cam=None, want_z=False, t_rand=None, sample_dist=None, want_scalars=False, color_stats=None):
+                query_cam=None, want_z=False, t_rand=None, sample_dist=None, want_scalars=False, color_stats=None, weight_cull=None, segment_rays=0):
+    if segment_rays:                       # O2345RenderIO.segment_rays: consecutive render() calls evaluated "together" -- here literally one oracle call per segment
+        parts = [render_rays(scene, rays_o[a:a + segment_rays], rays_d[a:a + segment_rays], near, far, n_samples, n_importance, inv_s, alpha_inter_ratio, background,
+                             query_cam, want_z, None if t_rand is None else t_rand[a:a + segment_rays], sample_dist, want_scalars, color_stats)
+                 for a in range(0, rays_o.shape[0], segment_rays)]
+        out = {}
+        for k in parts[0]:
+            if k == "scalars":
+                out[k] = torch.stack([p[k] for p in parts])
+            else:
+                sample_major = k in ("mid_z", "pm", "sdf", "grad", "weights", "cdf", "z_vals")
+                out[k] = torch.cat([p[k] for p in parts], dim=1 if sample_major else 0).contiguous()
+        return out
     W, RW = _SDF[scene["sdf_blob"].data_ptr()], _COL[scene["color_x3_blob"].data_ptr()]
     D = scene["vol_cl"].shape[0]
     fm, cm = _maps(scene["cmaps"])

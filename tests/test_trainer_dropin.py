@@ -204,6 +204,51 @@ def test_val_step_of_the_unchanged_trainer_default_perturb(ref_trainer):
     assert torch.equal(imgs[0], imgs[1]) and not torch.equal(imgs[0], imgs[2])
 
 
+def test_whole_image_mode_under_the_unchanged_trainer_loop(ref_trainer):
+    """The reference's OWN val_step loop (trainer_generic.py:503-524: `rays_o.reshape(-1, 3).split(chunk_size)`, one render() per chunk) drives the mirror's
+    whole-image mode: the chunks are views of one tensor, the first call renders every segment (O2345RenderIO.segment_rays; here through the CPU stand-in,
+    which evaluates the segments one oracle call each), the second call is a slice.  Pinned here: the HOST LOGIC -- view detection on the trainer's real
+    tensors, the interleaved host random stream (t_rand, pts_random per chunk), slicing, cache release -- by comparing every returned entry of every chunk
+    and the final generator state with the plain per-chunk calls (O2345_WHOLE_IMAGE=0) under the same seed.  The kernels' side of the same contract
+    (per-segment rules) is tests/test_gpu_segments.py."""
+    GenericTrainer, M = ref_trainer
+    D, HW = 14, 24
+    tr = _build(GenericTrainer, M, D)
+    sample, sc = _sample(4, HW)
+    ren = tr.sdf_renderer_lod0
+    orig = ren.render
+    vm = tr.validate_mesh
+    tr.validate_mesh = lambda *a, **k: vm(*a, **dict(k, resolution=12))
+    runs = {}
+    for mode in (False, True):
+        ren.whole_image, ren._abandoned, ren._image = mode, 0, None
+        outs, served = [], []
+
+        def spy(*a, **k):
+            had = ren._image is not None
+            out = orig(*a, **k)
+            outs.append({kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in out.items()})
+            served.append(had and ren._image is None or (had and ren._image is not None and ren._image["next"] > 1))
+            return out
+        ren.render = spy
+        torch.manual_seed(5)
+        tr.val_step(sample, background_rgb=None, alpha_inter_ratio_lod0=1.0, iter_step=0, chunk_size=512, save_vis=True)
+        runs[mode] = (outs, torch.get_rng_state(), served)
+        ren.render = orig
+    plain, fused = runs[False], runs[True]
+    assert len(plain[0]) == len(fused[0]) == 2 and plain[0][1]["depth"].shape[0] == 64
+    assert fused[2] == [False, True] and plain[2] == [False, False], "the second chunk of the image was served from the first call's fused render"
+    assert torch.equal(plain[1], fused[1]), "host generator state after the image"
+    for k, (a, b) in enumerate(zip(plain[0], fused[0])):
+        assert set(a) == set(b) and len(a) == 23
+        for key in a:
+            if a[key] is None:
+                assert b[key] is None
+            else:
+                assert a[key].shape == b[key].shape and torch.equal(a[key], b[key]), (k, key)
+    assert ren._image is None
+
+
 def test_reference_costregnet_on_the_torchsparse_shim(ref_trainer):
     """INTEGRATION.md's "shims only" level with the REFERENCE's own module code: tsparse/modules.py's SparseCostRegNet (:259-304, built from
     its BasicSparse{Conv,Deconv}olutionBlock) imports `torchsparse` = our shim (dropin hook) and runs through the shim's Conv3d / BatchNorm /
