@@ -22,6 +22,9 @@ def ply_header(n_vertices, n_faces, colors):
     return ("\n".join(lines) + "\n").encode("ascii")
 
 
+_WARNED = False
+
+
 def write_records(path, vertex_records, face_records, colors):
     """vertex_records / face_records: contiguous uint8 arrays (16 or 12 bytes per vertex, 13 per face)."""
     vertex_records = np.ascontiguousarray(vertex_records, np.uint8).reshape(-1)
@@ -45,10 +48,21 @@ def write_ply(path, vertices, faces, vertex_colors=None):
     c = None if vertex_colors is None else np.ascontiguousarray(vertex_colors, np.uint8)
     if c is not None and (c.ndim != 2 or c.shape[0] != v.shape[0] or c.shape[1] not in (3, 4)):
         raise ValueError(f"write_ply: vertex_colors must be [N,3] or [N,4] uint8 for N = {v.shape[0]} vertices, got {c.shape}")
+    try:
+        L = _lib.lib()
+    except (RuntimeError, OSError, AttributeError) as e:
+        # FILE FORMATTING on the host, not device work: without a loadable library (a machine that only converts meshes) the numpy writer produces the
+        # same bytes (tests/test_mesh_io.py), 6 - 8 ms slower per million records.  Every compute op still refuses to run without the library.
+        global _WARNED
+        if not _WARNED:
+            import warnings
+            warnings.warn(f"o2345 mesh_io.write_ply: libo2345_hip.so is not loadable ({e}); writing the PLY with the numpy packer (same bytes)")
+            _WARNED = True
+        return write_ply_numpy(path, v, f, c)
     vrec = np.empty((v.shape[0], 16 if c is not None else 12), np.uint8)
     frec = np.empty((f.shape[0], 13), np.uint8)
     P = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(ctypes.c_void_p)
-    _lib.check(_lib.lib().o2345_ply_records_host(P(v), v.shape[0], P(c), 0 if c is None else c.shape[1], P(f), f.shape[0], P(vrec), P(frec)), "ply_records_host")
+    _lib.check(L.o2345_ply_records_host(P(v), v.shape[0], P(c), 0 if c is None else c.shape[1], P(f), f.shape[0], P(vrec), P(frec)), "ply_records_host")
     write_records(path, vrec, frec, c is not None)
 
 

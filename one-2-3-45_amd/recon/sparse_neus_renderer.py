@@ -265,30 +265,35 @@ class SparseNeuSRenderer(nn.Module):
             # the host stream of the K calls of the trainer's loop, in the reference's order: per call t_rand = torch.rand(z_vals.shape) (:506-515, only when
             # perturb > 0), then pts_random = torch.rand([1024, 3]) (:606); the generator is then put back to where it stands after the FIRST call
             states, batches = [], []
-            for bi in range(0, K, KB):
-                k1 = min(K, bi + KB)
-                a0, a1 = bi * R, min(Ri, k1 * R)
-                t_b = torch.empty(a1 - a0, self.n_samples, pin_memory=pin) if perturb > 0 else None
-                p_b = torch.empty(k1 - bi, 1024, 3, pin_memory=pin)
-                for k in range(bi, k1):
-                    ra, rb = k * R - a0, min(Ri, (k + 1) * R) - a0
-                    if perturb > 0:
-                        t_b[ra:rb] = torch.rand(rb - ra, self.n_samples)
-                    p_b[k - bi] = torch.rand([1024, 3])
-                    states.append(torch.get_rng_state())
-                with (torch.cuda.stream(self._side) if nb > 1 else contextlib.nullcontext()):
-                    o = ops.render_rays(scene, io_[a0:a1], id_[a0:a1], nr, fr, self.n_samples, self.n_importance, inv_s, air, bg, qcam,
-                                        t_rand=t_b.to(dev, non_blocking=True) if perturb > 0 else None, want_scalars=True, segment_rays=R)
-                    pts_random = p_b.to(dev, non_blocking=True).view(-1, 3) * 2 - 1
-                    sdf_random = ops.sdf_mlp(scene["sdf_blob"], scene["vol_cl"], pts_random, variant=0)["sdf"].view(k1 - bi, 1024, 1)
-                    rows = dict(depth=o["depth"][:, None], color=o["color"], mask=o["color_mask"].view(torch.bool)[:, None], cdf=o["cdf"].t(),
-                                depth_var=o["depth_var"][:, None], weights_sum=o["weights_sum"][:, None], weights_max=o["weights_max"][:, None],
-                                grad=o["grad"].permute(1, 0, 2), weights=o["weights"].t(), pm=o["pm"].t(), sdf=o["sdf"].t())      # ray-major views: a chunk is a row range
-                    ev = None
-                    if nb > 1:
-                        ev = torch.cuda.Event()
-                        ev.record(self._side)
-                batches.append(dict(a0=a0, k0=bi, o=o, rows=rows, sdf_random=sdf_random, event=ev, joined=False))
+            rng_before = torch.get_rng_state()
+            try:
+                for bi in range(0, K, KB):
+                    k1 = min(K, bi + KB)
+                    a0, a1 = bi * R, min(Ri, k1 * R)
+                    t_b = torch.empty(a1 - a0, self.n_samples, pin_memory=pin) if perturb > 0 else None
+                    p_b = torch.empty(k1 - bi, 1024, 3, pin_memory=pin)
+                    for k in range(bi, k1):
+                        ra, rb = k * R - a0, min(Ri, (k + 1) * R) - a0
+                        if perturb > 0:
+                            t_b[ra:rb] = torch.rand(rb - ra, self.n_samples)
+                        p_b[k - bi] = torch.rand([1024, 3])
+                        states.append(torch.get_rng_state())
+                    with (torch.cuda.stream(self._side) if nb > 1 else contextlib.nullcontext()):
+                        o = ops.render_rays(scene, io_[a0:a1], id_[a0:a1], nr, fr, self.n_samples, self.n_importance, inv_s, air, bg, qcam,
+                                            t_rand=t_b.to(dev, non_blocking=True) if perturb > 0 else None, want_scalars=True, segment_rays=R)
+                        pts_random = p_b.to(dev, non_blocking=True).view(-1, 3) * 2 - 1
+                        sdf_random = ops.sdf_mlp(scene["sdf_blob"], scene["vol_cl"], pts_random, variant=0)["sdf"].view(k1 - bi, 1024, 1)
+                        rows = dict(depth=o["depth"][:, None], color=o["color"], mask=o["color_mask"].view(torch.bool)[:, None], cdf=o["cdf"].t(),
+                                    depth_var=o["depth_var"][:, None], weights_sum=o["weights_sum"][:, None], weights_max=o["weights_max"][:, None],
+                                    grad=o["grad"].permute(1, 0, 2), weights=o["weights"].t(), pm=o["pm"].t(), sdf=o["sdf"].t())      # ray-major views: a chunk is a row range
+                        ev = None
+                        if nb > 1:
+                            ev = torch.cuda.Event()
+                            ev.record(self._side)
+                    batches.append(dict(a0=a0, k0=bi, o=o, rows=rows, sdf_random=sdf_random, event=ev, joined=False))
+            except BaseException:
+                torch.set_rng_state(rng_before)                                  # a failed call must not leave the host generator advanced by a whole image
+                raise
             torch.set_rng_state(states[0])
             store = lambda t: (t.data_ptr(), t._version, t.numel())     # (the Python object of a view's base is not guaranteed to be the same one twice)
             args = (conditional_volume, conditional_valid_mask_volume, feature_maps, color_maps, w2cs, intrinsics, query_c2w)
