@@ -203,7 +203,7 @@ def main(which):
             for k in ("z", "sdf", "new_z"):
                 out[f"v{vi_}_up{i}_{k}"] = t[k].numpy()
             out[f"v{vi_}_up{i}_inv_s"] = np.float64(t["inv_s"])
-        if vi_ == 0:
+        if True:                                 # every variance: the reference against itself
             amax = float(dense.abs().max())
             for si, sigma in enumerate(SELFSENS_SIGMA):
                 ce, ze = [], []
@@ -213,11 +213,12 @@ def main(which):
                     rn, _ = render_chunks(renderer, sdfnet, rnet, sc, T, r_ro, r_rd, chunk, noisy, mask, fmaps, HW)
                     ce.append(np.abs(rn["color_fine"] - ren["color_fine"]).max(1))
                     ze.append(np.abs(rn["z_vals"] - ren["z_vals"]).max(1))
-                out[f"selfsens{si}_sigma"] = np.float64(sigma)
-                out[f"selfsens{si}_color_err"] = np.stack(ce).astype(np.float32)
-                out[f"selfsens{si}_z_err"] = np.stack(ze).astype(np.float32)
+                pre = f"selfsens{si}" if vi_ == 0 else f"v{vi_}_selfsens{si}"
+                out[f"{pre}_sigma"] = np.float64(sigma)
+                out[f"{pre}_color_err"] = np.stack(ce).astype(np.float32)
+                out[f"{pre}_z_err"] = np.stack(ze).astype(np.float32)
                 c = np.stack(ce).reshape(-1)
-                print(f"[{which}] reference vs itself on a volume perturbed by {sigma:g} x max: colour q50 / q90 / q99 / max {np.quantile(c, .5):.2e} "
+                print(f"[{which}] variance {variance}: reference vs itself on a volume perturbed by {sigma:g} x max: colour q50 / q90 / q99 / max {np.quantile(c, .5):.2e} "
                       f"{np.quantile(c, .9):.2e} {np.quantile(c, .99):.2e} {c.max():.2e}, > 1e-3: {(c > 1e-3).mean():.3f}, z max {np.stack(ze).max():.3f}", flush=True)
         print(f"[{which}] variance {variance}: {r_ro.shape[0]} rays, weights_sum max {float(ren['weights_sum'].max()):.4f}, "
               f"rays with weight > 0.5: {int((ren['weights_sum'] > 0.5).sum())}, colour-valid rays {int(ren['color_fine_mask'].sum())}, "

@@ -148,9 +148,10 @@ def end_to_end(G):
             same = zerr < 1e-6
             q = lambda t, x: float(torch.quantile(t, x))
             own = None
-            if vi == 0 and "selfsens0_color_err" in g.files:      # the REFERENCE against itself on a volume that differs by fp32-class noise (make_golden_scale.SELFSENS_*)
-                sc_, sz_ = torch.from_numpy(g["selfsens0_color_err"]).reshape(-1), torch.from_numpy(g["selfsens0_z_err"])
-                own = {"volume_noise_sigma_over_absmax": float(g["selfsens0_sigma"]), "color_err_q50_q90_q99_max": [q(sc_, 0.5), q(sc_, 0.9), q(sc_, 0.99), float(sc_.max())],
+            pre = "selfsens0" if vi == 0 else f"v{vi}_selfsens0"
+            if pre + "_color_err" in g.files:                     # the REFERENCE against itself on a volume that differs by fp32-class noise (make_golden_scale.SELFSENS_*)
+                sc_, sz_ = torch.from_numpy(g[pre + "_color_err"]).reshape(-1), torch.from_numpy(g[pre + "_z_err"])
+                own = {"volume_noise_sigma_over_absmax": float(g[pre + "_sigma"]), "color_err_q50_q90_q99_max": [q(sc_, 0.5), q(sc_, 0.9), q(sc_, 0.99), float(sc_.max())],
                        "frac_rays_color_gt_1e-3": float((sc_ > 1e-3).float().mean()), "z_err_max": float(sz_.max())}
             out.append({"variance": variance, "inv_s": wt.inv_s, "rays": int(len(pos)), "coarse_spacing": (G["far"] - G["near"]) / 63,
                         "reference_vs_itself_on_a_noisy_volume": own,

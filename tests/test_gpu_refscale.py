@@ -81,7 +81,7 @@ def test_render_end_to_end_vs_reference(G):
         amp = max(1.0, e["inv_s"] / 20.0)
         assert e["color_err_max_on_coinciding_lists"] <= TOL["core_color"] * amp, e
         own = e["reference_vs_itself_on_a_noisy_volume"]
-        if own is not None:                      # (the trained-variance subset is reported, not capped: inv_s = 148 turns every list difference into an O(1) colour difference)
+        if own is not None:                      # (also for the trained variance: inv_s = 148 turns a list difference into an O(1) colour difference -- in the reference too)
             for hip, ref in zip(e["color_err_q50_q90_q99_max"][:3], own["color_err_q50_q90_q99_max"][:3]):
                 assert hip <= TOL["e2e_vs_own_quantiles"] * ref + 1e-5, e
             assert e["color_err_q50_q90_q99_max"][3] <= TOL["e2e_vs_own_max"] * own["color_err_q50_q90_q99_max"][3], e
