@@ -53,8 +53,6 @@ def main():
         o0["depth"].detach().cpu().numpy(); o0["color_fine"].detach().cpu().numpy()
         (o0["gradients"] * o0["weights"][:, :S, None] * o0["inside_sphere"][..., None]).sum(dim=1).detach().cpu().numpy()
     out["trainer_own_per_chunk_work_128x_ms"] = (time.perf_counter() - t0) * 1e3
-    # the fused call alone (no segments, no host RNG)
-    pipeline = __import__("importlib").import_module("one-2-3-45_amd.pipeline")
     print(json.dumps(out, indent=1))
 
 
