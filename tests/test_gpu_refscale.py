@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 # ---- the stated tolerances, HIP vs reference at these sizes (max abs error / max(1, max |reference|) unless noted; measured values: DESIGN.md section 4)
 TOL = dict(fmaps=2e-5, feats16=2e-5, dense=5e-5, dense_rms=3e-6,
            sampler_abs=2e-4, sampler_bin=5e-3, sampler_floor=5e-7,
-           core_color=1e-4, core_depth=5e-5, core_weights=5e-5, core_sdf=5e-5, core_grad=2e-4,
+           core_color=1e-4, core_depth=6e-5, core_weights=6e-5, core_sdf=5e-5, core_grad=2e-4,
            e2e_vs_own_quantiles=3.0, e2e_vs_own_max=2.0, u=5e-5)
 
 
