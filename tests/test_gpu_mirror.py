@@ -237,6 +237,58 @@ def test_whole_image_behind_the_chunk_loop_equals_the_per_chunk_calls(S, scale):
         ren.whole_image, ren._image, ren._abandoned = True, None, 0
 
 
+def test_two_threads_render_two_images_concurrently(S):
+    """nn.DataParallel-style use on ONE device: two host threads, each with its own renderer object and its own torch stream, run the trainer's chunk loop
+    over two different images at the same time (whole-image mode: each renderer launches its batches on its own side stream; the threads share torch's
+    host generator, so a thread regularly finds the generator moved by the other one and falls back to a plain call for that chunk -- by design).  Every
+    chunk of both images must equal the sequential single-thread result (deterministic sampling; `sdf_random` depends on the shared generator and is not
+    compared)."""
+    import threading
+    pkg = importlib.import_module("one-2-3-45_amd")
+    g, G, T = S["G"]["g"], S["G"], S["T"]
+    sc, HW = G["sc"], G["cfg"]["HW"]
+    ro, rd = pkg.synth.gen_rays(sc["query_intrinsic"], sc["query_c2w"], HW, HW, scale=4)          # 25,600 rays: four batches on a side stream
+    imgs = [(T(ro)[None], T(rd)[None]), (T(ro[::-1].copy())[None], T(rd[::-1].copy())[None])]
+    dense, mask = T(g["dense"])[None], T(g["mask"])[None, None]
+    kw = dict(perturb_overwrite=0, background_rgb=1.0, alpha_inter_ratio=1.0, lod=0, conditional_volume=dense, conditional_valid_mask_volume=mask,
+              feature_maps=T(G["fmaps"]), color_maps=T(sc["images"]), w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW],
+              query_c2w=T(sc["query_c2w"])[None], if_render_with_grad=False)
+    near, far = T(sc["query_near_far"][:1]), T(sc["query_near_far"][1:])
+    rens = [recon.SparseNeuSRenderer(None, S["sdf"], S["var"], S["rnet"], 64, 64, 0, 1.0, alpha_type="div", conf=Conf({"general.base_exp_dir": "/tmp"})) for _ in range(2)]
+    keys = ("color_fine", "depth", "weights", "weights_sum", "gradients", "inside_sphere", "color_fine_mask", "sdf")
+
+    def loop(i, out):
+        o_, d_ = imgs[i]
+        res = [rens[i].render(a, b, near, far, S["sdf"], S["rnet"], **kw) for a, b in zip(o_[0].reshape(-1, 3).split(512), d_[0].reshape(-1, 3).split(512))]
+        out[i] = [{k: r[k].clone() for k in keys} for r in res]
+    seq = {}
+    for i in range(2):
+        loop(i, seq)
+    torch.cuda.synchronize()
+    con, errs = {}, []
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                loop(i, con)
+                streams[i].synchronize()
+        except Exception as e:                                       # noqa: BLE001
+            errs.append(e)
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(2):
+        assert len(con[i]) == len(seq[i]) == 50
+        for k, (a, b) in enumerate(zip(seq[i], con[i])):
+            for key in keys:
+                assert torch.equal(a[key], b[key]), (i, k, key)
+
+
 def test_render_core_mirror_on_the_references_lists(S):
     """SparseNeuSRenderer.render_core in the reference's call form (:171-455) on the sample lists the REFERENCE's render() produced with a trained model's
     variance (tests/golden/ref_trained.npz): the reference's own per-ray results."""
