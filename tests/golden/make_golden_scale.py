@@ -5,6 +5,7 @@ runner's 512-ray chunks -> extract_fields -- on the configurations BASELINE.json
     python tests/golden/make_golden_scale.py c1        # -> ref_c1.npz          BASELINE config 1, exactly: V = 8 ring, 64^3, 64 seeded rays, 64 + 64, perturb 0
     python tests/golden/make_golden_scale.py c2        # -> ref_c2_sample.npz   BASELINE config 2: 128^3, 8 x 512-ray chunks (= 8 rows) of the 512^2 image
     python tests/golden/make_golden_scale.py ref       # -> ref_refcfg_sample.npz   the reference configuration: V = 32, 96^3, 2 chunks of the 256^2 val image
+    python tests/golden/make_golden_scale.py c5        # -> ref_c5_lod1_sample.npz  BASELINE config 5's sparse 256^3 level: the coarse-to-fine path on config 2's scene
 
 A file stores seeds, the networks' state dicts and OUTPUTS only: the images / cameras / rays are regenerated from the seeds by `inputs()` on the machine
 that runs the comparison (numpy Generator streams and the closed-form camera rig are platform-stable; checksums are stored and checked).  Nothing here is
@@ -249,7 +250,113 @@ def main(which):
     print(f"wrote {path} {os.path.getsize(path) // 1024} KiB in {time.time() - T0:.0f} s")
 
 
+# ---- BASELINE config 5's sparse 256^3 level: the reference's coarse-to-fine path (trainer_generic.py:437-491) on config 2's scene ----------------------
+C5 = dict(name="ref_c5_lod1_sample.npz", base="c2", net_seed=31, rows=(232,), n_dense=50000, n_pts=20000)
+
+
+def lod1_networks(D1, seed):
+    """The reference's lod-1 SparseSdfNetwork (confs/one2345_lod_train.conf:83-96: 8 compressed channels, parent feature concatenated) + its own rendering /
+    variance networks, seeded, zero-initialised paths perturbed like make_golden.main()."""
+    from oracle import ref_import as RI
+    R = RI.load()
+    torch.manual_seed(seed)
+    sdf1 = R.SparseSdfNetwork(lod=1, ch_in=56, voxel_size=2.0 / (D1 - 1), vol_dims=[D1] * 3, hidden_dim=128, cost_type="variance_mean",
+                              d_pyramid_feature_compress=8, regnet_d_out=16, num_sdf_layers=4, multires=6)
+    g1 = torch.Generator().manual_seed(seed)
+    sdf1.sdf_layer.lin0.weight_v.data[:, 3:] += 0.003 * torch.randn(128, 36, generator=g1)
+    sdf1.sdf_layer.lin1.weight_v.data[:, 128:] += 0.03 * torch.randn(128, 16, generator=g1)
+    sdf1.sdf_layer.lin2.weight_v.data[:, 128:] += 0.03 * torch.randn(128, 16, generator=g1)
+    for m in sdf1.sparse_costreg_net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data = 1 + 0.2 * torch.randn(m.weight.shape, generator=g1)
+            m.bias.data = 0.1 * torch.randn(m.bias.shape, generator=g1)
+    sdf1.compress_layer.bn.weight.data = (1 + 0.2 * torch.randn(8, generator=g1)) * torch.tensor([1.0, -1.0, 1.0, 1.0, -1.0, 1.0, 1.0, 1.0])
+    sdf1.compress_layer.bn.bias.data = 0.1 * torch.randn(8, generator=g1)
+    rnet1 = R.GeneralRenderingNetwork(in_geometry_feat_ch=16, in_rendering_feat_ch=56, anti_alias_pooling=True)
+    var1 = R.SingleVarianceNetwork(0.2)
+    conf = RI.Conf({"general.base_exp_dir": "/tmp", "model.h_patch_size": 3})
+    ren1 = R.SparseNeuSRenderer(None, sdf1, var1, rnet1, 64, 64, 0, 1.0, alpha_type="div", conf=conf)
+    return sdf1, rnet1, var1, ren1
+
+
+@torch.no_grad()
+def main_c5():
+    c5, cfg = C5, CONFIGS[C5["base"]]
+    sc, ro, rd, sel, chunk = inputs(cfg)
+    V, D, HW = cfg["V"], cfg["D"], 256
+    D1 = 2 * D
+    T = torch.from_numpy
+    fnet, sdfnet, rnet, var, renderer = build_reference_networks(cfg)
+    out = {}
+    out.update(checksums(sc, ro, rd))
+    fmaps = fused_pyramid(fnet, T(sc["images"]))
+    origin = T(sc["partial_vol_origin"])[None]
+    cv = sdfnet.get_conditional_volume(feature_maps=fmaps[None], partial_vol_origin=origin, proj_mats=T(sc["affine_mats"])[None], sizeH=HW, sizeW=HW, lod=0)
+    dense, mask, coords = cv["dense_volume_scale0"], cv["valid_mask_volume_scale0"], cv["coords_scale0"]
+    print(f"[c5] lod-0 volume {int(mask.sum())} voxels, {time.time() - T0:.0f} s", flush=True)
+    # ---- trainer_generic.py:437-440
+    sv = sdfnet.get_sdf_volume(dense, mask, coords, origin)
+    rng = np.random.default_rng(c5["net_seed"])
+    kept = np.nonzero(mask.reshape(-1).numpy() > 0)[0]
+    vi = np.sort(rng.choice(kept, 100000, replace=False))
+    out["l0_sdf_idx"], out["l0_sdf_val"] = vi.astype(np.int64), sv.reshape(-1)[vi].numpy()
+    out["l0_sdf_bits_below_thr"] = np.packbits((sv.reshape(-1).abs() < 0.02).numpy())          # |sdf| < the pruning threshold, every voxel
+    # ---- :470-472 (no depth filter): the default threshold 0.02, stepping down while more than 110,000 voxels remain
+    np.random.seed(0)
+    pc, pf = renderer.get_valid_sparse_coords_by_sdf(sv[0], coords[0], mask[0], dense[0])
+    assert pc.shape[0] <= 110000, "the unseeded np.random.choice branch fired: this scene cannot pin the selection"
+    out["pre_coords"] = pc[:, 1:].numpy().astype(np.int16)
+    # the threshold the loop ended on: the largest one of the sequence 0.02, 0.018, ... that keeps <= 110,000 voxels
+    print(f"[c5] pruned lod-0 voxels {pc.shape[0]}, {time.time() - T0:.0f} s", flush=True)
+    pc2 = pc.clone()
+    pc2[:, 1:] = pc2[:, 1:] * 2                                                                 # :474
+    sdf1, rnet1, var1, ren1 = lod1_networks(D1, c5["net_seed"])
+    cv1 = sdf1.get_conditional_volume(feature_maps=fmaps[None], partial_vol_origin=origin, proj_mats=T(sc["affine_mats"])[None], sizeH=HW, sizeW=HW,
+                                      pre_coords=pc2, pre_feats=pf)
+    dense1, mask1 = cv1["dense_volume_scale1"], cv1["valid_mask_volume_scale1"]
+    m1 = mask1.reshape(-1).numpy() > 0
+    out["l1_kept_voxels"] = np.int64(m1.sum())
+    out["l1_mask_bits"] = np.packbits(m1)
+    k1 = np.nonzero(m1)[0]
+    v1 = np.sort(rng.choice(k1, min(c5["n_dense"], k1.size), replace=False))
+    out["l1_dense_idx"], out["l1_dense_val"] = v1.astype(np.int64), dense1[0].reshape(16, -1)[:, v1].t().contiguous().numpy()
+    out["l1_dense_absmax"] = np.float32(dense1.abs().max())
+    print(f"[c5] lod-1 volume {D1}^3: {int(m1.sum())} children kept of {8 * pc.shape[0]}, {time.time() - T0:.0f} s", flush=True)
+    # ---- SDF of the lod-1 network at points around the kept voxels
+    ctr = torch.stack(torch.meshgrid(*[torch.arange(D1, dtype=torch.float32)] * 3, indexing="ij"), -1).reshape(-1, 3)[T(k1[rng.choice(k1.size, c5["n_pts"])])]
+    pts = (ctr * (2.0 / (D1 - 1)) + origin.reshape(1, 3) + T(rng.uniform(-0.004, 0.004, (c5["n_pts"], 3)).astype(np.float32))).contiguous()
+    out["l1_pts"] = pts.numpy()
+    out["l1_sdf"] = sdf1.sdf(pts.clone(), dense1, 1)["sdf_pts_scale1"].numpy()
+    # ---- one chunk of the lod-1 val loop (trainer_generic.py:540-566)
+    W = 256 * cfg["ray_scale"]
+    keep = np.concatenate([np.nonzero((sel // W) == r)[0] for r in c5["rows"]])
+    out["ray_pos"] = keep.astype(np.int64)
+    ren, trace = render_chunks(ren1, sdf1, rnet1, sc, T, ro[keep], rd[keep], chunk, dense1, mask1, fmaps, HW)
+    for k in REN_KEYS + ("z_vals", "weights"):
+        out["v0_" + k] = ren[k]
+    out["v0_variance"] = np.float64(0.2)
+    amax = float(dense1.abs().max())
+    ce, ze = [], []
+    for seed in SELFSENS_SEEDS:
+        gsd = torch.Generator().manual_seed(seed)
+        noisy = dense1 + (SELFSENS_SIGMA[0] * amax) * torch.randn(dense1.shape, generator=gsd) * mask1
+        rn, _ = render_chunks(ren1, sdf1, rnet1, sc, T, ro[keep], rd[keep], chunk, noisy, mask1, fmaps, HW)
+        ce.append(np.abs(rn["color_fine"] - ren["color_fine"]).max(1)); ze.append(np.abs(rn["z_vals"] - ren["z_vals"]).max(1))
+        noisy = None
+    out["selfsens0_sigma"], out["selfsens0_color_err"], out["selfsens0_z_err"] = np.float64(SELFSENS_SIGMA[0]), np.stack(ce).astype(np.float32), np.stack(ze).astype(np.float32)
+    print(f"[c5] lod-1 render: {len(keep)} rays, weights_sum max {float(ren['weights_sum'].max()):.4f}, rays with weight > 0.5: {int((ren['weights_sum'] > 0.5).sum())}; "
+          f"reference vs itself colour q50 / q99 / max {np.quantile(np.stack(ce), .5):.2e} {np.quantile(np.stack(ce), .99):.2e} {np.stack(ce).max():.2e}, {time.time() - T0:.0f} s", flush=True)
+    for prefix, net in (("fnet.", fnet), ("sdf.", sdfnet), ("sdf1.", sdf1), ("ren1.", rnet1)):
+        for k, v in net.state_dict().items():
+            if "num_batches_tracked" in k or "running_" in k:
+                continue
+            out["w:" + prefix + k] = v.numpy()
+    path = os.path.join(HERE, c5["name"])
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} {os.path.getsize(path) // 1024} KiB in {time.time() - T0:.0f} s")
+
+
 if __name__ == "__main__":
     torch.set_grad_enabled(False)
     for w in (sys.argv[1:] or ["c1"]):
-        main(w)
+        main_c5() if w == "c5" else main(w)

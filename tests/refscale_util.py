@@ -199,3 +199,103 @@ def report(name, dev=None, precision=None):
     G = load(name, dev, precision)
     return {"golden": G["cfg"]["name"], "generator": "tests/golden/make_golden_scale.py (the imported reference modules, CPU)", "volume": volume(G),
             "sampler_on_reference_inputs": sampler(G), "render_core_on_reference_lists": core(G), "render_end_to_end": end_to_end(G), "extract_fields": field(G)}
+
+
+# ---- BASELINE config 5's sparse 256^3 level (tests/golden/ref_c5_lod1_sample.npz): the coarse-to-fine path through the MIRROR modules, like the trainer ----
+def lod1(dev=None):
+    """trainer_generic.py:437-491 on config 2's scene with recon.* : get_sdf_volume -> get_valid_sparse_coords_by_sdf -> x2 -> lod-1 get_conditional_volume
+    (256^3 sparse) -> sdf() -> render() at lod 1, each against the reference's outputs.  -> dict of measured numbers."""
+    import make_golden_scale as MS
+    recon = importlib.import_module("one-2-3-45_amd.recon")
+    fn = importlib.import_module("one-2-3-45_amd.featurenet")
+    c5, cfg = MS.C5, MS.CONFIGS[MS.C5["base"]]
+    g = np.load(os.path.join(HERE, "golden", c5["name"]))
+    sc, ro, rd, sel, chunk = MS.inputs(cfg)
+    for k, v in MS.checksums(sc, ro, rd).items():
+        assert v == g[k], f"input {k} differs from the one the golden file was generated on"
+    dev = dev or torch.device("cuda:0")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    w = lambda p: {k[len("w:" + p):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w:" + p)}
+    D, HW = cfg["D"], 256
+    D1 = 2 * D
+
+    class Conf(dict):
+        def get_int(self, k, default=None):
+            return int(self.get(k, default))
+    mk = lambda lod, dims, comp: recon.SparseSdfNetwork(lod=lod, ch_in=56, voxel_size=2.0 / (dims - 1), vol_dims=[dims] * 3, hidden_dim=128, cost_type="variance_mean",
+                                                        d_pyramid_feature_compress=comp, regnet_d_out=16, num_sdf_layers=4, multires=6).to(dev)
+    sdf0, sdf1 = mk(0, D, 16), mk(1, D1, 8)
+    for net, sd in ((sdf0, w("sdf.")), (sdf1, w("sdf1."))):
+        miss = net.load_state_dict(sd, strict=False)
+        assert not miss.unexpected_keys and all("running_" in k or "num_batches" in k for k in miss.missing_keys), miss
+    fnet = fn.FeatureNet().to(dev)
+    miss = fnet.load_state_dict(w("fnet."), strict=False)
+    assert not miss.unexpected_keys
+    rnet1 = recon.GeneralRenderingNetwork(16, 56, True).to(dev)
+    rnet1.load_state_dict(w("ren1."))
+    var1 = recon.SingleVarianceNetwork(0.2).to(dev)
+    ren1 = recon.SparseNeuSRenderer(None, sdf1, var1, rnet1, 64, 64, 0, 1.0, alpha_type="div", conf=Conf({"general.base_exp_dir": "/tmp"}))
+    res = {"golden": c5["name"]}
+    with torch.no_grad():
+        imgs = T(sc["images"])
+        fmaps = fn.fused_pyramid(fnet, imgs)
+        origin, aff = T(sc["partial_vol_origin"])[None], T(sc["affine_mats"])[None]
+        cv0 = sdf0.get_conditional_volume(feature_maps=fmaps[None], partial_vol_origin=origin, proj_mats=aff, sizeH=HW, sizeW=HW, lod=0)
+        dense, mask, lattice = cv0["dense_volume_scale0"], cv0["valid_mask_volume_scale0"], cv0["coords_scale0"]
+        # ---- get_sdf_volume (sparse_sdf_network.py:441-474)
+        sv = sdf0.get_sdf_volume(dense, mask, lattice, origin)
+        res["l0_sdf_volume"] = relerr(sv.reshape(-1)[torch.from_numpy(g["l0_sdf_idx"]).to(dev)], g["l0_sdf_val"])
+        below = (sv.reshape(-1).abs() < 0.02).cpu().numpy()
+        ref_below = np.unpackbits(g["l0_sdf_bits_below_thr"])[: below.size].astype(bool)
+        diff = np.nonzero(below != ref_below)[0]
+        res["l0_voxels_below_threshold"] = [int(below.sum()), int(ref_below.sum())]
+        res["l0_threshold_disagreements"] = int(diff.size)
+        res["l0_threshold_disagreements_band"] = float((sv.reshape(-1)[torch.from_numpy(diff).to(dev)].abs() - 0.02).abs().max()) if diff.size else 0.0
+        # ---- get_valid_sparse_coords_by_sdf (sparse_neus_renderer.py:822-879): the mirror's own selection vs the reference's
+        pc, pf = ren1.get_valid_sparse_coords_by_sdf(sv[0], lattice[0], mask[0], dense[0])
+        ref_pc = torch.from_numpy(g["pre_coords"].astype(np.int64))
+        key = lambda c: (c[:, 0] * D + c[:, 1]) * D + c[:, 2]
+        a_, b_ = set(key(pc[:, 1:].long().cpu()).tolist()), set(key(ref_pc).tolist())
+        res["pruned_voxels"] = [len(a_), len(b_)]
+        res["pruned_voxels_symmetric_difference"] = len(a_ ^ b_)
+        res["pruned_order_equal"] = bool(len(a_ ^ b_) == 0 and torch.equal(pc[:, 1:].long().cpu(), ref_pc))
+        # ---- the lod-1 volume on the REFERENCE's selection (the discrete part compared exactly), features from HIP's own lod-0 volume
+        rp = ref_pc.to(dev)
+        pf_ref = dense[0].reshape(16, -1).t()[key(rp)].contiguous()
+        pc2 = torch.cat([torch.zeros(rp.shape[0], 1, device=dev), rp.float() * 2], 1)                        # trainer_generic.py:474
+        cv1 = sdf1.get_conditional_volume(feature_maps=fmaps[None], partial_vol_origin=origin, proj_mats=aff, sizeH=HW, sizeW=HW, pre_coords=pc2, pre_feats=pf_ref)
+        dense1, mask1 = cv1["dense_volume_scale1"], cv1["valid_mask_volume_scale1"]
+        m1 = (mask1.reshape(-1) > 0).cpu().numpy()
+        res["l1_kept_voxels"] = [int(m1.sum()), int(g["l1_kept_voxels"])]
+        res["l1_mask_bits_exact"] = bool(np.array_equal(np.packbits(m1), g["l1_mask_bits"]))
+        res["l1_dense_volume"] = relerr(dense1[0].reshape(16, -1)[:, torch.from_numpy(g["l1_dense_idx"]).to(dev)].t(), g["l1_dense_val"], float(g["l1_dense_absmax"]))
+        res["l1_sdf"] = relerr(sdf1.sdf(T(g["l1_pts"]), dense1, 1)["sdf_pts_scale1"], g["l1_sdf"])
+        # ---- one chunk of the lod-1 val loop
+        pos = g["ray_pos"]
+        kw = dict(background_rgb=1.0, alpha_inter_ratio=1.0, lod=1, conditional_volume=dense1, conditional_valid_mask_volume=mask1, feature_maps=fmaps,
+                  color_maps=imgs, w2cs=T(sc["w2cs"]), intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW], query_c2w=T(sc["query_c2w"])[None], if_render_with_grad=False)
+        near, far = T(sc["query_near_far"][:1]), T(sc["query_near_far"][1:])
+        sd = (float(sc["query_near_far"][1]) - float(sc["query_near_far"][0])) / 64
+        rc = ren1.render_core(T(ro[pos]), T(rd[pos]), T(g["v0_z_vals"]), sd, 1, sdf1, rnet1, **{k: v for k, v in kw.items() if k != "lod"})
+        res["render_core_on_reference_lists"] = {
+            "color": relerr(rc["color"], g["v0_color_fine"]), "depth": relerr(rc["depth"], g["v0_depth"]), "weights": relerr(rc["weights"], g["v0_weights"]),
+            "weights_sum": relerr(rc["weights_sum"], g["v0_weights_sum"]),
+            "color_mask_mismatches": int((rc["color_mask"].cpu() != torch.from_numpy(g["v0_color_fine_mask"])).sum())}
+        seen = []
+        real = ops.render_rays
+        ops.render_rays = lambda *a, **k: (lambda o: (seen.append(o["z_vals"].t().cpu()), o)[1])(real(*a, **dict(k, want_z=True)))
+        try:
+            out = ren1.render(T(ro[pos]), T(rd[pos]), near, far, sdf1, rnet1, perturb_overwrite=0, **kw)
+        finally:
+            ops.render_rays = real
+        cerr = (out["color_fine"].cpu() - torch.from_numpy(g["v0_color_fine"])).abs().max(1).values
+        zerr = (seen[-1] - torch.from_numpy(g["v0_z_vals"])).abs().max(1).values
+        own = torch.from_numpy(g["selfsens0_color_err"]).reshape(-1)
+        q = lambda t, x: float(torch.quantile(t, x))
+        same = zerr < 1e-6
+        res["render_end_to_end"] = {"rays": int(len(pos)), "color_err_q50_q90_q99_max": [q(cerr, 0.5), q(cerr, 0.9), q(cerr, 0.99), float(cerr.max())],
+                                    "reference_vs_itself_color_err_q50_q90_q99_max": [q(own, 0.5), q(own, 0.9), q(own, 0.99), float(own.max())],
+                                    "z_err_max": float(zerr.max()), "reference_vs_itself_z_err_max": float(g["selfsens0_z_err"].max()),
+                                    "rays_with_coinciding_lists": int(same.sum()), "color_err_max_on_coinciding_lists": float(cerr[same].max()) if same.any() else 0.0,
+                                    "color_mask_mismatches": int((out["color_fine_mask"].cpu() != torch.from_numpy(g["v0_color_fine_mask"])).sum())}
+    return res

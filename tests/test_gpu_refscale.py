@@ -99,3 +99,27 @@ def test_extract_fields_vs_reference(G):
     assert r["sign_flips"] <= 2 and r["abs_u_reference_at_flips_max"] <= r["field_err_max"], "a lattice node may change sign only inside the field's own error band"
     if r["sign_flips"] == 0:
         assert r["triangles_identical"] and r["vertex_shift_max_cells"] < 0.02, r
+
+
+def test_lod1_sparse_256_cubed_vs_reference():
+    """BASELINE config 5's sparse 256^3 level: the reference's coarse-to-fine path (trainer_generic.py:437-491; rows a13, a26, f2 of SURVEY 8) on config 2's
+    scene, through the mirror modules, against tests/golden/ref_c5_lod1_sample.npz (the imported reference, make_golden_scale.py c5): get_sdf_volume at the
+    1.17 M kept voxels, the pruning selection (60,324 voxels: the mirror's own selection may differ from the reference's only where |sdf| is within the
+    field's error band of the 0.02 threshold), the lod-1 volume built on the REFERENCE's selection (every one of the 16.7 M mask bits, dense samples), the
+    lod-1 SDF, and one 512-ray chunk of the lod-1 val loop."""
+    r = RU.lod1()
+    print(f"[refscale c5 / lod 1] {json.dumps(r)}", file=sys.stderr)
+    assert r["l0_sdf_volume"] < 2e-5, r
+    assert r["l0_threshold_disagreements"] <= 20 and r["l0_threshold_disagreements_band"] <= 5e-5, r
+    assert r["pruned_voxels_symmetric_difference"] <= 60, r          # (a threshold flip reaches the selection through the 7^3 dilation)
+    assert r["l1_mask_bits_exact"] and r["l1_kept_voxels"][0] == r["l1_kept_voxels"][1], r
+    assert r["l1_dense_volume"] < 5e-5 and r["l1_sdf"] < 5e-5, r
+    c = r["render_core_on_reference_lists"]
+    assert c["color_mask_mismatches"] == 0 and c["color"] < TOL["core_color"] and c["depth"] < TOL["core_depth"], r
+    assert max(c["weights"], c["weights_sum"]) < TOL["core_weights"], r
+    e = r["render_end_to_end"]
+    assert e["color_mask_mismatches"] == 0 and e["color_err_max_on_coinciding_lists"] <= TOL["core_color"], r
+    for hip, ref in zip(e["color_err_q50_q90_q99_max"][:3], e["reference_vs_itself_color_err_q50_q90_q99_max"][:3]):
+        assert hip <= TOL["e2e_vs_own_quantiles"] * ref + 1e-5, r
+    assert e["color_err_q50_q90_q99_max"][3] <= TOL["e2e_vs_own_max"] * e["reference_vs_itself_color_err_q50_q90_q99_max"][3], r
+    assert e["z_err_max"] <= TOL["e2e_vs_own_max"] * e["reference_vs_itself_z_err_max"], r
