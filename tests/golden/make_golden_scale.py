@@ -235,6 +235,22 @@ def main(which):
         ins = u > 0
         print(f"[{which}] extract_fields {R}^3: {int(ins.sum())} inside nodes, sign changes along x {int((ins[1:] != ins[:-1]).sum())}, "
               f"{time.time() - T0:.0f} s", flush=True)
+        # ---- validate_colored_mesh (trainer_generic.py:1309-1363) on vertices of that field's surface: view-independent projector (normals = the SDF's
+        # autograd gradient) + the rendering network.  (mcubes is not installed: the vertices come from the checker's marching cubes on the reference's u.)
+        from oracle import mc as omc
+        v_idx, _ = omc.marching_cubes(u, 0.0)
+        if len(v_idx):
+            pick = np.sort(rng.choice(len(v_idx), min(4000, len(v_idx)), replace=False))
+            vw = v_idx[pick] / (R - 1.0) * (bmax.numpy() - bmin.numpy())[None, :] + bmin.numpy()[None, :]          # sparse_neus_renderer.py:936
+            vp = torch.tensor(vw).to(dense)                                                                        # trainer_generic.py:1327 (float64 -> float32)
+            with torch.enable_grad():
+                geo, rf, rdiff, vm, _, _ = renderer.rendering_projector.compute_view_independent(
+                    vp.clone(), lod=0, geometryVolume=dense[0], geometryVolumeMask=mask[0], sdf_network=sdfnet, rendering_feature_maps=fmaps,
+                    color_maps=T(sc["images"]), w2cs=T(sc["w2cs"]), target_candidate_w2cs=None, intrinsics=T(sc["intrinsics"]), img_wh=[HW, HW],
+                    query_img_idx=0, query_c2w=T(sc["query_c2w"])[None])
+            vcol, _ = rnet(geo.detach(), rf.detach(), rdiff.detach(), vm)
+            out["vert_pts"], out["vert_rgb"], out["vert_mask"] = vp.numpy(), vcol[0].detach().numpy(), vm[:, 0].numpy()
+            print(f"[{which}] vertex colours: {len(pick)} of {len(v_idx)} vertices, {time.time() - T0:.0f} s", flush=True)
     # ---- state dicts (parameters only: the reference runs every normalisation layer on batch statistics)
     for prefix, net in (("fnet.", fnet), ("sdf.", sdfnet), ("ren.", rnet), ("var.", var)):
         for k, v in net.state_dict().items():

@@ -194,11 +194,27 @@ def field(G):
     return res
 
 
+def vertex_colours(G):
+    """validate_colored_mesh's colouring (trainer_generic.py:1309-1363: compute_view_independent with the SDF gradient as the query direction + the rendering
+    network) on vertices of the reference field's surface vs the reference's colours; valid-view counts exact."""
+    g, wt, vol, sc_ = G["g"], G["wt"], G["vol"], G["scene"]
+    if "vert_pts" not in g.files:
+        return None
+    pts = G["T"](g["vert_pts"])
+    grad = ops.sdf_mlp(wt.sdf_blob, vol["vol_cl"], pts, variant=2, precision=wt.sdf_precision)["grad"]
+    x3 = wt.color_precision == "f16x3"
+    rgb, nv = ops.color_points(wt.color_xblob if x3 else wt.color_mblob, vol["vol_cl"], vol["maskvol"], vol["cmaps"], sc_["proj"], sc_["cam_pos"], pts, normals=grad,
+                               mfma="x3" if x3 else True)
+    want_nv = g["vert_mask"].sum(0).astype(np.uint8)
+    return {"vertices": int(pts.shape[0]), "rgb": relerr(rgb, g["vert_rgb"]), "valid_view_count_mismatches": int((nv.cpu().numpy() != want_nv).sum()),
+            "vertices_seen_by_two_or_more_views": int((want_nv >= 2).sum())}
+
+
 def report(name, dev=None, precision=None):
     """Everything above for one golden file as one JSON-able dict (bench.py's `parity_reference` block)."""
     G = load(name, dev, precision)
     return {"golden": G["cfg"]["name"], "generator": "tests/golden/make_golden_scale.py (the imported reference modules, CPU)", "volume": volume(G),
-            "sampler_on_reference_inputs": sampler(G), "render_core_on_reference_lists": core(G), "render_end_to_end": end_to_end(G), "extract_fields": field(G)}
+            "sampler_on_reference_inputs": sampler(G), "render_core_on_reference_lists": core(G), "render_end_to_end": end_to_end(G), "extract_fields": field(G), "vertex_colours": vertex_colours(G)}
 
 
 # ---- BASELINE config 5's sparse 256^3 level (tests/golden/ref_c5_lod1_sample.npz): the coarse-to-fine path through the MIRROR modules, like the trainer ----

@@ -101,6 +101,16 @@ def test_extract_fields_vs_reference(G):
         assert r["triangles_identical"] and r["vertex_shift_max_cells"] < 0.02, r
 
 
+def test_vertex_colours_vs_reference(G):
+    """validate_colored_mesh (trainer_generic.py:1309-1363; row a25): the view-independent Projector (query direction = the SDF's gradient, autograd in the
+    reference, analytic here) + GeneralRenderingNetwork on up to 4,000 vertices of the reference field's surface -> the reference's vertex colours; the
+    valid-view count of every vertex exact."""
+    r = RU.vertex_colours(G)
+    show(G, "vertex colours vs REFERENCE", r)
+    assert r is not None and r["vertices"] > 1000 and r["vertices_seen_by_two_or_more_views"] > 100, r
+    assert r["valid_view_count_mismatches"] == 0 and r["rgb"] < 2e-4, r
+
+
 def test_lod1_sparse_256_cubed_vs_reference():
     """BASELINE config 5's sparse 256^3 level: the reference's coarse-to-fine path (trainer_generic.py:437-491; rows a13, a26, f2 of SURVEY 8) on config 2's
     scene, through the mirror modules, against tests/golden/ref_c5_lod1_sample.npz (the imported reference, make_golden_scale.py c5): get_sdf_volume at the
