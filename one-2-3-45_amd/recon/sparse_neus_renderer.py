@@ -145,7 +145,7 @@ class SparseNeuSRenderer(nn.Module):
 
     def _pack_rows(self, c, a, b, k):
         """The returned dict of chunk k = rays [a, b) of the cached image c."""
-        bt = c["batches"][k // c["KB"]]
+        bt = c["batches"][c["batch_of"][k]]
         if not bt["joined"]:                       # first chunk of a batch rendered on the side stream: the caller's stream waits for THAT batch only, and the
             bt["joined"] = True                    # caching allocator learns that the batch's buffers are used on the caller's stream too
             if bt["event"] is not None:
@@ -256,7 +256,15 @@ class SparseNeuSRenderer(nn.Module):
             # draws the next -- and later, while the trainer pulls chunk after chunk to the host (a .cpu() per chunk on ITS stream), the GPU is still rendering
             # the following batches.  A chunk waits only for its own batch (one event per batch), not for the image.
             nb = max(1, min(self.image_batches, Ri // 4096)) if dev.type == "cuda" else 1          # (a batch of >= 4,096 rays runs the streaming sampler kernels)
-            KB = (K + nb - 1) // nb
+            # batch boundaries in chunks: equal batches, except that the LAST one is a third of the others -- what the host does with a batch's chunks (serve + the
+            # trainer's own .cpu() calls, ~0.11 ms per chunk) only overlaps the rendering of LATER batches, so the last batch's share is pure tail
+            if nb > 1 and os.environ.get("O2345_IMAGE_TAIL", "1") not in ("", "0"):
+                big = -(-K * 3 // (3 * nb - 2))
+                starts = [min(K, i * big) for i in range(nb)]
+            else:
+                starts = [min(K, i * ((K + nb - 1) // nb)) for i in range(nb)]
+            starts = sorted(set(starts))
+            bounds = [(k0, k1) for k0, k1 in zip(starts, starts[1:] + [K]) if k1 > k0]
             cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
             if nb > 1:
                 if self._side is None or self._side.device != dev:
@@ -267,8 +275,7 @@ class SparseNeuSRenderer(nn.Module):
             states, batches = [], []
             rng_before = torch.get_rng_state()
             try:
-                for bi in range(0, K, KB):
-                    k1 = min(K, bi + KB)
+                for bi, k1 in bounds:
                     a0, a1 = bi * R, min(Ri, k1 * R)
                     t_b = torch.empty(a1 - a0, self.n_samples, pin_memory=pin) if perturb > 0 else None
                     p_b = torch.empty(k1 - bi, 1024, 3, pin_memory=pin)
@@ -298,7 +305,8 @@ class SparseNeuSRenderer(nn.Module):
             store = lambda t: (t.data_ptr(), t._version, t.numel())     # (the Python object of a view's base is not guaranteed to be the same one twice)
             args = (conditional_volume, conditional_valid_mask_volume, feature_maps, color_maps, w2cs, intrinsics, query_c2w)
             # (scene / bases: the packed weights and ray storages stay alive while cached, so their addresses cannot be handed to other tensors)
-            self._image = dict(n=R, R=Ri, KB=KB, next=1, states=states, batches=batches, scene=scene, bases=bases, store=(store(bases[0]), store(bases[1])),
+            batch_of = [b for b, (k0, k1) in enumerate(bounds) for _ in range(k0, k1)]
+            self._image = dict(n=R, R=Ri, batch_of=batch_of, next=1, states=states, batches=batches, scene=scene, bases=bases, store=(store(bases[0]), store(bases[1])),
                                args=[(t, t._version) for t in args], near=(near, getattr(near, "_version", None)), far=(far, getattr(far, "_version", None)),
                                perturb=float(perturb) > 0, air=alpha_inter_ratio, bg=background_rgb, var=(var, var._version), inv_s=inv_s,
                                wkeys=(sdf_network.sdf_layer.weights_key(), rendering_network.weights_key()), nets=(sdf_network, rendering_network),
