@@ -140,7 +140,9 @@ def camera_terms(intrinsics, w2cs):
 def render(wt, vol, proj, cam_pos, rays_o, rays_d, near, far, query_cam, n_samples=64, n_importance=64, want_z=False, t_rand=None):
     """One call renders all rays (no 512-ray chunks).  ``t_rand`` [R, n_samples]: the reference's perturb > 0 jitter (drawn by the caller).
     Note: the reference's per-512-ray-chunk quirks (cat_z_vals skipped when <= 1 new point of the CHUNK is valid; "first 100 points"
-    when a chunk has no valid point) apply per CALL here -- identical when called per chunk, as the drop-in mirror does."""
+    when a chunk has no valid point) apply per CALL here -- identical when called per chunk, as the drop-in mirror does (or per segment of one
+    call: ops.render_rays(segment_rays=...)).  The colour network skips occupied samples whose compositing weight is below config.WEIGHT_CULL
+    (2^-24: a ray's colour moves by <= 7.6e-6, nothing else changes; O2345_WEIGHT_CULL=0 = every occupied sample, like the reference)."""
     scene = dict(sdf_blob=wt.sdf_blob, vol_cl=vol["vol_cl"], maskvol=vol["maskvol"],
                  cmaps=vol["cmaps"], proj=proj, cam_pos=cam_pos, color_mfma_blob=wt.color_mblob,
                  sdf_precision=wt.sdf_precision, color_precision=wt.color_precision,
