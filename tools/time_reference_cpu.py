@@ -60,11 +60,36 @@ def main():
     renderer.extract_fields(torch.tensor([-1.0] * 3), torch.tensor([1.0] * 3), R, lambda p, **kw: sdfnet.sdf(p, **kw), "cpu",
                             conditional_volume=dense, lod=0)
     de = time.time() - t1
+    # ---- the volume build of the same configuration, per stage (FeatureNet, pyramid, get_conditional_volume), on seeded images
+    stages = {}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import make_golden_scale as MS
+        cfg = MS.CONFIGS["c2"]
+        fnet, sdf2, rnet2, var2, ren2 = MS.build_reference_networks(cfg)
+        imgs = T(sc["images"])
+        tick = time.time()
+        fm2 = MS.fused_pyramid(fnet, imgs)
+        stages["featurenet_fused_pyramid_s"] = time.time() - tick
+        tick = time.time()
+        f16 = sdf2.compress_layer(fm2)
+        stages["compress_layer_s"] = time.time() - tick
+        tick = time.time()
+        cv2 = sdf2.get_conditional_volume(feature_maps=fm2[None], partial_vol_origin=T(sc["partial_vol_origin"])[None], proj_mats=T(sc["affine_mats"])[None],
+                                          sizeH=HW, sizeW=HW, lod=0)
+        stages["get_conditional_volume_s"] = time.time() - tick
+        stages["kept_voxels"] = int(cv2["valid_mask_volume_scale0"].sum())
+        stages["note"] = ("get_conditional_volume = compress layer + both back_project_sparse_type passes + aggregation + SparseCostRegNet (torchsparse stand-in: "
+                          "oracle/recon.py's gather-GEMM-scatter restatement) + dense scatter")
+        del cv2, fm2, f16
+    except Exception as e:                               # noqa: BLE001  (the render timing above is the number bench.py needs)
+        stages["error"] = f"{type(e).__name__}: {e}"
     out = {"what": "the reference's own SparseNeuSRenderer.render / extract_fields (models/sparse_neus_renderer.py:457-635, 881-905) on CPU, "
                    "BASELINE config-2 inputs (8 views 256^2, 128^3 volume); where it was measured: _meta.host / _meta.cpu / cores",
            "value": done / dt, "unit": "rays/s", "cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "kind": "reference",
            "sample": f"{done} rays in 512-ray chunks (the runner's batch size), {dt:.1f} s",
-           "extract_fields_points_per_s": R ** 3 / de, "extract_fields_sample": f"{R}^3 grid, {de:.1f} s (a 256^3 grid is 64x that)"}
+           "extract_fields_points_per_s": R ** 3 / de, "extract_fields_sample": f"{R}^3 grid, {de:.1f} s (a 256^3 grid is 64x that)",
+           "volume_build_stages": stages}
     import datetime
     import platform
     import subprocess
