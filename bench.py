@@ -17,12 +17,12 @@ N > 1: one process per GPU, every rank reconstructs its own scenes: embarrassing
 -> "scaling": "weak".  `python bench.py --gpus N` works bare: when WORLD_SIZE is not set it re-executes itself under
 `python -m torch.distributed.run --nproc-per-node N` (rendezvous on 127.0.0.1); under an existing torchrun launch it uses that.
 
-Besides the contract's line (config 2), rank 0 attaches: `parity_fullsize` (the cpu_baseline rays compared with the HIP outputs),
-`c3` (BASELINE config 3: 32 distinct scenes dealt over the ranks, inputs uploaded host->device inside the step), `ref_config`
-(the reference's own V=32 / 96^3 / 256^3 configuration), `config5` (256^3 volume, 1024^2 rays, 512^3 grid), `fp32_whole_step_ms`,
-`cpu_baseline_reference` (the reference's own modules timed on a GPU box's host cores: tools/reference_cpu_on_gpu_box.sh), `parity_reference` (HIP vs the
-reference's own outputs at BASELINE config 2 / 1: tests/golden/ref_c2_sample.npz, ref_c1.npz), `trained_regime` (a trained model's variance: what the
-weight-bounded colour work removal buys).  `--quick` skips them.
+Output (rank 0): the LAST stdout line is the contract line, compact (<= 4 KB, contract_line()): metric / value / ms_per_step / config / dtype, `roofline`
+of the dominant kernel, {frac, ms} of the other three, `cpu_baseline` (the reference's own modules as timed on this host type when the stamped file of this
+round matches, kind "reference"; else the oracle port timed live, kind "port") and one max-error number per stage vs the reference (`parity`).  The full
+record -- `parity_fullsize`, `c3` (BASELINE config 3), `ref_config` (V=32 / 96^3 / 256^3), `config5` (256^3 / 1024^2 / 512^3), `fp32_whole_step_ms`,
+`cpu_baseline_reference`, `parity_reference` detail, `trained_regime`, `pipelined`, `dropin` -- is the stdout line BEFORE it and bench_extra.json.
+`--quick` skips the extra blocks.
 """
 import argparse
 import importlib
@@ -367,7 +367,7 @@ def cpu_baseline_and_parity(wt, vol, inp, D, n_rays, budget_s=15.0):
                 T=lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
     n = full["ro"].shape[0]
     ref, sel, dt = FU.oracle_render_sample(full, n_rays, budget_s=budget_s)
-    cpu = {"value": len(sel) / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+    cpu = {"value": len(sel) / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": this_host()["cpu"],
            "sample": f"{len(sel)} of the {n} rays of the same scene (oracle.render, {FU.CHUNK}-ray chunks, fp32), {dt:.1f} s"}
     par = {"rays": int(len(sel)), "oracle": "oracle/recon.py (pinned to the reference by tests/golden + tests/test_oracle_vs_reference.py)"}
     sub = slice(0, min(len(sel), 512))                             # the downstream / stage checks re-run oracle stages: bounded subset
@@ -405,7 +405,7 @@ def cpu_baseline_and_parity(wt, vol, inp, D, n_rays, budget_s=15.0):
     return cpu, par
 
 
-CURRENT_ROUND = 5
+CURRENT_ROUND = 6
 
 
 def this_host():
@@ -443,6 +443,22 @@ def cpu_reference_file():
     cands.sort(key=lambda c: (c[0], c[1]))
     same, f, d = cands[-1]
     return dict(d, source=os.path.relpath(f, ROOT), same_host_type=bool(same), this_host=here)
+
+
+def merge_cpu_baseline(port, ref):
+    """The `cpu_baseline` object of the line.  Preferred: the REFERENCE's own modules (kind "reference") as timed on a host of THIS box's CPU model and
+    core count (profiles/rNN_cpu_reference_gpubox.json, tools/reference_cpu_on_gpu_box.sh -- the reference tree does not exist on the box at bench time);
+    the oracle port timed live in this run rides along as port_rays_per_s.  When the stamped file is missing, stale or from another host type the live
+    port measurement is the value (kind "port") and `reference` says why the reference number was refused."""
+    port = port or {}
+    if ref and ref.get("value") and ref.get("same_host_type"):
+        meta = ref.get("_meta") or {}
+        return {"value": ref["value"], "unit": ref.get("unit", "rays/s"), "cores": ref.get("torch_threads") or ref.get("cores"), "torch_threads": ref.get("torch_threads"),
+                "host_cores": ref.get("cores"), "kind": "reference", "cpu": meta.get("cpu"), "same_host_type": True, "sample": ref.get("sample"),
+                "source": ref.get("source"), "port_rays_per_s": port.get("value"), "port_sample": port.get("sample")}
+    why = (ref or {}).get("refused") or (f"{ref.get('source')} was measured on {(ref.get('_meta') or {}).get('cpu')} x{(ref.get('_meta') or {}).get('nproc')}, this box is "
+                                        f"{ref.get('this_host')}: {ref.get('value'):.0f} rays/s there" if ref and ref.get("value") else "no stamped reference timing")
+    return dict(port, same_host_type=False, reference={"value": None, "refused": why})
 
 
 def parity_reference_block(dev, precision):
@@ -564,6 +580,107 @@ def dropin_block(dev):
                       "reference_published_export_mesh_ms": 2488.7,
                       "speedup_vs_published_fresh_process": (2488.7 / out["fresh_process_2"]["export_mesh_first_call_ms"]) if out["fresh_process_2"].get("export_mesh_first_call_ms") else None}
     return out
+
+
+LINE_BUDGET = 4096             # bytes: the driver keeps only the tail of stdout (BENCH_r05.json: a 23 KB line -> `parsed: null`)
+
+
+def _r(x, n=5):
+    """Numbers rounded to n significant digits (the compact line is for a parser and a reader, not for bit-level provenance: that is bench_extra.json)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}")
+    if isinstance(x, (list, tuple)):
+        return [_r(v, n) for v in x]
+    if isinstance(x, dict):
+        return {k: _r(v, n) for k, v in x.items()}
+    return x
+
+
+def _parity_summary(ref):
+    """One max-error number per stage from `parity_reference` (HIP vs the reference's own outputs, tests/golden/ref_c{1,2}*.npz)."""
+    out = {}
+    for name in ("c1", "c2"):
+        p = (ref or {}).get(name)
+        if not isinstance(p, dict):
+            continue
+        rc = (p.get("render_core_on_reference_lists") or [{}])[0]
+        e2e = (p.get("render_end_to_end") or [{}])[0]
+        ef, vc, vol, smp = p.get("extract_fields") or {}, p.get("vertex_colours") or {}, p.get("volume") or {}, p.get("sampler_on_reference_inputs") or {}
+        out[name] = {"mask_bits_exact": vol.get("mask_bits_exact"), "dense_volume": vol.get("dense_volume"), "sampler_dz": smp.get("dz_max"),
+                     "sdf": rc.get("sdf"), "grad": rc.get("grad"), "core_color": rc.get("color"), "core_depth": rc.get("depth"), "core_weights": rc.get("weights"),
+                     "e2e_color_q99": (e2e.get("color_err_q50_q90_q99_max") or [None] * 4)[2],
+                     "ref_self_sensitivity_q99": ((e2e.get("reference_vs_itself_on_a_noisy_volume") or {}).get("color_err_q50_q90_q99_max") or [None] * 4)[2],
+                     "field": ef.get("field_err_max"), "sign_flips": ef.get("sign_flips"), "triangles_identical": ef.get("triangles_identical"),
+                     "vertex_rgb": vc.get("rgb")}
+        out[name] = {k: v for k, v in out[name].items() if v is not None}
+    if (ref or {}).get("refused"):
+        out["refused"] = ref["refused"]
+    return out
+
+
+def contract_line(result):
+    """The ONE line the driver parses: the contract's keys + roofline + cpu_baseline + one parity number per stage, <= LINE_BUDGET bytes.  Everything else
+    of `result` (c3, pipelined, trained_regime, ref_config, config5, dropin, parity detail, issue model ...) goes to bench_extra.json and to an EARLIER stdout line."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "shared_gpu_functional_run", "rccl_ranks", "backend")
+    line = {k: result[k] for k in keep if k in result}
+    cfg = result.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "views", "volume", "rays", "mesh_res", "parallelism", "precision", "variance", "weight_cull", "weights") if k in cfg}
+    if len(str(line["config"].get("workload", ""))) > 400:
+        line["config"]["workload"] = line["config"]["workload"][:397] + "..."
+    for k in ("render_rays_per_s", "render_ms", "mesh_extract_ms", "volume_build_ms"):
+        if k in result:
+            line[k] = result[k]
+    if result.get("per_rank"):                              # N > 1: every rank's own clock (a straggler GPU shows here)
+        line["per_rank_ms"] = [r.get("ms_per_step_own_clock") for r in result["per_rank"]]
+    if "exhaustive_colour" in result:                       # the reference's work item for item (weight_cull = 0), same scenes and steps
+        line["exhaustive"] = {"value": result["exhaustive_colour"]["value"], "ms_per_step": result["exhaustive_colour"]["ms_per_step"]}
+    rl = result.get("roofline")
+    if rl:
+        ev = rl.get("pairs_evaluated_network_pass")
+        line["roofline"] = {"kernel": rl["kernel"].split(" ")[0], "bound": rl["bound"], "achieved": rl["achieved"], "peak": rl["peak"], "unit": rl["unit"],
+                            "frac": rl["frac"],
+                            "frac_on_evaluated_pairs": (rl["frac"] * ev * 32.0 / rl["units"]) if ev and rl.get("units") else None,
+                            "ms": rl["ms"], "units": rl.get("units"), "flop_per_unit": rl.get("flop_per_unit"),
+                            "mfma_busy_frac": (rl.get("rocprof") or {}).get("mfma_busy_frac"), "traffic": rl.get("traffic"),
+                            "algorithmic_bytes": rl.get("algorithmic_bytes")}
+    for k in ("roofline_sdf", "roofline_sdf_grad", "roofline_costvol"):
+        if k in result:
+            line[k] = {"frac": result[k]["frac"], "ms": result[k]["ms"]}
+    if "cpu_baseline" in result:
+        line["cpu_baseline"] = result["cpu_baseline"]
+    par = _parity_summary(result.get("parity_reference"))
+    if par:
+        line["parity"] = par
+    line["extra"] = "bench_extra.json + the previous stdout line"
+    line = _r(line)
+    line["value"], line["ms_per_step"] = result["value"], result["ms_per_step"]          # the two contract numbers unrounded
+    s = json.dumps(line, separators=(",", ":"))
+    for drop in ("parity", "exhaustive", "roofline_costvol", "roofline_sdf_grad", "roofline_sdf"):          # never exceed the budget: shed detail, keep the contract
+        if len(s) <= LINE_BUDGET:
+            break
+        line.pop(drop, None)
+        line["dropped_for_size"] = line.get("dropped_for_size", []) + [drop]
+        s = json.dumps(line, separators=(",", ":"))
+    assert len(s) <= LINE_BUDGET, len(s)
+    return s
+
+
+def emit(result):
+    """bench_extra.json (next to bench.py and, on a gpurun box, under gpurun_out/), the full record as an earlier stdout line, the contract line LAST."""
+    full = json.dumps(result)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_extra.json"), "w") as f:
+                    f.write(full + "\n")
+            except OSError:
+                pass
+    sys.stderr.flush()
+    print(full)
+    print(contract_line(result), flush=True)
 
 
 def reexec_under_torchrun(n):
@@ -737,7 +854,10 @@ def main():
             "list_sort_ms": kt.get("list_sort_ms"),      # csrc/list_sort.hip: the occupied-point list grouped by view-visibility signature (inside every render call)
             # dominant kernel of a step = the colour network: ALGORITHMIC FLOP (38,544 per (point, view)) x occupied
             # points x views / HIP-event time of that launch, against the dense MFMA peak of the type the matrix pipe runs in
+            # algorithmic_bytes of the colour kernel = every input byte once: 28 B per occupied point (xyz, list index, rgb out) + the latent volume + mask + colour/feature maps
             "roofline": dict(rl["color"], traffic=pmc_traffic(COLOR_KERNEL_PREFIX),
+                             algorithmic_bytes=int(nvp * 28 + vol["vol_cl"].numel() * vol["vol_cl"].element_size() + vol["maskvol"].numel() * vol["maskvol"].element_size()
+                                                   + vol["cmaps"].numel() * vol["cmaps"].element_size()),
                              traffic_source=(f"{PMC_FILE} (bytes, 2*FETCH_SIZE+WRITE_SIZE; collected on these kernel sources)" if PMC_DATA is not None else PMC_STALE),
                              issue_model=pmc_issue_model(COLOR_KERNEL_PREFIX, kt["color_ms"]), rocprof=pmc_mfma_busy(COLOR_KERNEL_PREFIX + "<true")),
             "roofline_sdf": dict(rl["sdf"], rocprof=pmc_mfma_busy("k_sdf_mlp_x3<false>" if wt.sdf_precision == "f16x3" else "k_sdf_mlp<0>"),
@@ -760,8 +880,10 @@ def main():
             result["roofline_fp32_mode"] = network_rooflines(kf, V, "fp32", "fp32")
         if world == 1 and not a.no_cpu:
             vol0 = pipeline.build_volume(wt, inp["imgs"], inp["aff"], inp["origin"], a.vol, 2.0 / (a.vol - 1))     # the scene cpu_baseline's images belong to
-            result["cpu_baseline"], result["parity_fullsize"] = cpu_baseline_and_parity(wt, vol0, inp, a.vol, a.cpu_rays)
+            port, result["parity_fullsize"] = cpu_baseline_and_parity(wt, vol0, inp, a.vol, a.cpu_rays)
             result["cpu_baseline_reference"] = cpu_reference_file()
+            result["cpu_baseline_port"] = port
+            result["cpu_baseline"] = merge_cpu_baseline(port, result["cpu_baseline_reference"])
             result["parity_reference"] = parity_reference_block(dev, a.precision)
             vol0 = None
         if world == 1 and not a.quick:
@@ -779,8 +901,9 @@ def main():
             torch.cuda.empty_cache()
             if not a.no_dropin:
                 result["dropin"] = dropin_block(dev)
-        print(json.dumps(result))
     sharding.shutdown()
+    if result is not None:
+        emit(result)                                # nothing may follow the contract line on stdout
 
 
 if __name__ == "__main__":

@@ -42,7 +42,9 @@ def color_precision(p=None):
 # 6 % of the occupied samples at the untrained variance 0.2 (inv_s 7.4), 27 % / 47 % at a trained model's 0.45 / 0.65 (bench.py, `trained_regime`);
 # free-space samples keep the reference's +1e-5 (w ~ 1e-5) and are never dropped.  O2345_WEIGHT_CULL=0 selects the exhaustive path (every occupied
 # sample, the reference's work); both are tested.
-WEIGHT_CULL = float(os.environ.get("O2345_WEIGHT_CULL", 2.0 ** -24))
+# The bound assumes blended colours in [0, 1] (the reference's colour maps are images in [0, 1], One2345_eval_new_data.py:199-201; the blend is a convex
+# combination of them): for maps of another range the bound scales with that range -- set O2345_WEIGHT_CULL accordingly.  "" or "0" = off, like the other knobs.
+WEIGHT_CULL = float(os.environ.get("O2345_WEIGHT_CULL", "").strip() or 0.0) if "O2345_WEIGHT_CULL" in os.environ else 2.0 ** -24
 if not (0.0 <= WEIGHT_CULL < 1.0):
     raise ValueError(f"O2345_WEIGHT_CULL must be in [0, 1), got {WEIGHT_CULL}")
 

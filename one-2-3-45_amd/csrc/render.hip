@@ -111,7 +111,7 @@ __device__ __forceinline__ bool seg_keeps_default(const RoundArgs& a, int r) { r
 // The reference's two per-CALL rules on the emitted list, applied by the round kernel itself instead of a one-thread launch each (six launches of the
 // 22 of a 512-ray chunk): the workgroup that finishes LAST (a.done counts finished workgroups) sees the final count and
 //   up-sampling round  cat_z_vals (:137): the SDF of the new samples is evaluated only if MORE THAN ONE of them is inside the mask -> count <= 1 becomes 0;
-//   finalize           render_core (:222-223): with no occupied point at all the first 100 points of the chunk (ray 0, samples 0..99 in the
+//   finalize           render_core (:222-223): with no occupied point at all the first 100 points of the chunk (ray 0, samples 0..99, in the
 //                      reference's ray-major order) are evaluated anyway.
 // Without a.done (the stage entry points) the launches k_quirk_min2 / nothing follow as before.
 // Ordering without fences: `count` and `done` are only ever touched by agent-scope atomic read-modify-writes, which are performed at the device's
@@ -128,12 +128,17 @@ __device__ __forceinline__ void round_epilogue(const RoundArgs& a, int S) {
     if (threadIdx.x == 0) last = atomicAdd(a.done, 1) == (int)gridDim.x - 1;
     __syncthreads();
     if (!last) return;
-    if (a.seg_rays) {                                // render_core's rule per segment: a segment without any occupied point evaluates its first ray's samples 0..99
-        const int n = 100 < S ? 100 : S;
+    // (the reference sets pts_mask_bool[:100] on the RAY-MAJOR flattened [N_rays * S] mask: point t is (ray t / S, sample t % S) -- with S < 100 the rule
+    //  runs on into the next rays; slots here are sample-major, s * R + r)
+    if (a.seg_rays) {                                // render_core's rule per segment: a segment without any occupied point evaluates its first 100 points
         for (int k = threadIdx.x; k < a.n_seg; k += blockDim.x) {
             if (atomicAdd(a.seg_cnt + k, 0) >= 1) continue;
+            const int r0 = k * a.seg_rays;
+            const int rays = (a.g.R - r0) < a.seg_rays ? (a.g.R - r0) : a.seg_rays;
+            const long long avail = (long long)rays * S;
+            const int n = avail < 100 ? (int)avail : 100;
             const int base = atomicAdd(a.count, n);
-            for (int t = 0; t < n; ++t) a.list[base + t] = t * a.g.R + k * a.seg_rays;
+            for (int t = 0; t < n; ++t) a.list[base + t] = (t % S) * a.g.R + r0 + t / S;
             atomicExch(a.seg_cnt + k, n);             // the segment's "evaluated points" (scalars[3])
         }
         return;
@@ -142,8 +147,9 @@ __device__ __forceinline__ void round_epilogue(const RoundArgs& a, int S) {
     if (MODE == RM_UPSAMPLE) {
         if (threadIdx.x == 0 && c <= 1) atomicExch(a.count, 0);
     } else if (c < 1) {
-        const int n = 100 < S ? 100 : S;
-        for (int t = threadIdx.x; t < n; t += blockDim.x) a.list[t] = t * a.g.R;     // slot of (ray 0, sample t)
+        const long long avail = (long long)a.g.R * S;
+        const int n = avail < 100 ? (int)avail : 100;
+        for (int t = threadIdx.x; t < n; t += blockDim.x) a.list[t] = (t % S) * a.g.R + t / S;     // slot of (ray t / S, sample t % S)
         if (threadIdx.x == 0) atomicExch(a.count, n);
     }
 }

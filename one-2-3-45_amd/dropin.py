@@ -69,6 +69,16 @@ def install():
         sys.meta_path.insert(0, _AliasFinder())
 
 
+def _report_whole_image():
+    """One line at exit: which path the val images took (recon.sparse_neus_renderer.WHOLE_IMAGE_TOTALS) -- rendered whole behind the trainer's chunk loop, or
+    fallen back to per-chunk calls and why (e.g. "rng" under nn.DataParallel on several devices: the device threads share torch's host generator)."""
+    mod = sys.modules.get(f"{PKG}.recon.sparse_neus_renderer") or sys.modules.get("models.sparse_neus_renderer")
+    st = getattr(mod, "WHOLE_IMAGE_TOTALS", None)
+    if st and (st["images"] or st["plain_calls"]):
+        print(f"o2345 render(): {st['images']} image(s) rendered whole, {st['chunks_served']} chunk(s) served from them, {st['plain_calls']} plain call(s), "
+              f"fallbacks by reason: {st['fallbacks_by_reason'] or 'none'}", file=sys.stderr)
+
+
 def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
@@ -76,6 +86,8 @@ def main():
     for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ.setdefault(var, str(cpu_threads()))
     install()
+    import atexit
+    atexit.register(_report_whole_image)
     script = sys.argv[1]
     sys.argv = sys.argv[1:]
     sys.path.insert(0, os.path.dirname(os.path.abspath(script)))

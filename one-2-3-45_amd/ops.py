@@ -709,9 +709,10 @@ def render_core(scene, rays_o, rays_d, z, sample_dist, inv_s, alpha_inter_ratio=
     V, H, W, _ = scene["cmaps"].shape
     o = ray_finalize(rays_o, rays_d, z, sample_dist, scene["maskvol"], D)
     n = int(o["count"])                                        # (a stage composition on the host: one read-back; o2345_render_rays keeps the count on the device)
-    if n < 1:                                                  # :222-223 -- ray 0's samples 0..99 in the reference's ray-major order
-        n = min(100, S)
-        o["list"][:n] = torch.arange(n, dtype=torch.int32, device=z.device) * R
+    if n < 1:                                                  # :222-223 -- the first 100 points in the reference's ray-major order: point t = (ray t // S, sample t % S)
+        n = min(100, S * R)
+        t = torch.arange(n, dtype=torch.int32, device=z.device)
+        o["list"][:n] = (t % S) * R + t // S
     lst = o["list"][:n].contiguous()
     pts = o["pts"].view(-1, 3)
     sdf_precision = config.sdf_precision(scene.get("sdf_precision"))

@@ -72,6 +72,23 @@ class SceneWeights:
         return self
 
 
+    @staticmethod
+    def _read_checkpoint(path, names, allow_pickle=None):
+        import os
+        if allow_pickle is None:
+            allow_pickle = os.environ.get("O2345_ALLOW_PICKLE", "0") not in ("", "0")
+        try:                                   # only float tensors are kept, so the restricted unpickler is enough for a well-formed checkpoint
+            ck = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception as e:                 # checkpoints that carry optimizer / numpy scalars need the full unpickler (the reference's own loader uses it)
+            if not allow_pickle:
+                raise RuntimeError(f"o2345 SceneWeights.from_checkpoint: {path!r} does not load with the restricted unpickler ({type(e).__name__}: {e}); "
+                                   "pass allow_pickle=True (or O2345_ALLOW_PICKLE=1) only for a checkpoint you trust -- the full unpickler runs code "
+                                   "from the file") from e
+            import warnings
+            warnings.warn(f"o2345: loading {path!r} with the FULL unpickler (allow_pickle): code in the file is executed")
+            ck = torch.load(path, map_location="cpu", weights_only=False)
+        return {n: {k: v for k, v in ck[n].items() if torch.is_tensor(v) and v.is_floating_point()} for n in names}
+
     @classmethod
     def from_checkpoint(cls, device, path, broadcast=False, sdf_precision=None, color_precision=None, allow_pickle=None):
         """Every rank builds its weights from ONE checkpoint file in the reference's format (exp_runner_generic_blender_val.py:514-541: keys
@@ -88,20 +105,12 @@ class SceneWeights:
             raise RuntimeError("SceneWeights.from_checkpoint(broadcast=True) needs an initialised torch.distributed process group (sharding.init)")
         state = None
         if not broadcast or dist.get_rank() == 0:
-            import os
-            if allow_pickle is None:
-                allow_pickle = os.environ.get("O2345_ALLOW_PICKLE", "0") not in ("", "0")
-            try:                                   # only float tensors are kept, so the restricted unpickler is enough for a well-formed checkpoint
-                ck = torch.load(path, map_location="cpu", weights_only=True)
-            except Exception as e:                 # checkpoints that carry optimizer / numpy scalars need the full unpickler (the reference's own loader uses it)
-                if not allow_pickle:
-                    raise RuntimeError(f"o2345 SceneWeights.from_checkpoint: {path!r} does not load with the restricted unpickler ({type(e).__name__}: {e}); "
-                                       "pass allow_pickle=True (or O2345_ALLOW_PICKLE=1) only for a checkpoint you trust -- the full unpickler runs code "
-                                       "from the file") from e
-                import warnings
-                warnings.warn(f"o2345: loading {path!r} with the FULL unpickler (allow_pickle): code in the file is executed")
-                ck = torch.load(path, map_location="cpu", weights_only=False)
-            state = {n: {k: v for k, v in ck[n].items() if torch.is_tensor(v) and v.is_floating_point()} for n in names}
+            try:
+                state = cls._read_checkpoint(path, names, allow_pickle)
+            except Exception as e:                 # with broadcast=True the other ranks are about to enter the collective: hand them the failure instead of a hang
+                if not broadcast:
+                    raise
+                state = e
         if broadcast:
             state = sharding.broadcast_state_dicts(state, device)
         return cls.from_state_dicts(device, state["sdf_network_lod0"], state["rendering_network_lod0"], state["variance_network_lod0"]["variance"],

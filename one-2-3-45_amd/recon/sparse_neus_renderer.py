@@ -12,6 +12,10 @@ from .rendering_network import DeferredColour
 from .sparse_sdf_network import _attr_cache, channel_last
 
 
+# process-wide sums of every renderer's whole-image counters (SparseNeuSRenderer.whole_image_stats); dropin.py prints them once at exit
+WHOLE_IMAGE_TOTALS = dict(images=0, chunks_served=0, plain_calls=0, fallbacks_by_reason={})
+
+
 def _scene_maps(feature_maps, color_maps, w2cs, intrinsics):
     """-> (colour map [V,H,W,64] = rgb | features | pad, proj [V,3,4], cam_pos [V,3]) of the scene's source views (models/projector.py:96-228 gathers from
     them); cached per tensor object + version."""
@@ -84,6 +88,7 @@ class SparseNeuSRenderer(nn.Module):
         self.rendering_projector = Projector()
         self.if_fitted_rendering = False
         self._image, self._abandoned, self._side = None, 0, None         # whole-image mode (render())
+        self._stats = dict(images=0, chunks_served=0, plain_calls=0, fallbacks_by_reason={})
 
     @torch.no_grad()
     def get_pts_mask_for_conditional_volume(self, pts, mask_volume):
@@ -126,9 +131,44 @@ class SparseNeuSRenderer(nn.Module):
     # cache: the same ray tensors (object, storage, version), the same scene / network / scalar arguments, the expected position in the image, and that
     # torch's host generator is exactly where the previous chunk left it (then it is advanced as the chunk's own draws would have).  Anything else falls
     # back to a plain call.  O2345_WHOLE_IMAGE=0 disables the mode.
+    # Which path an image took is observable: ``whole_image_stats()`` (per renderer) / ``WHOLE_IMAGE_TOTALS`` (process-wide, printed once at exit by dropin.py):
+    # images rendered whole, chunks served as slices, plain calls, and the fallbacks by reason -- "rng" (somebody else drew from torch's host generator, e.g.
+    # nn.DataParallel's other device threads), "args" (other scene / scalar arguments), "weights", "order" (not the next chunk), "rays" (other ray tensors),
+    # "oom" (the image did not fit: the mode switches itself off for this renderer and the call is served as a plain call).
     whole_image = os.environ.get("O2345_WHOLE_IMAGE", "1") not in ("", "0")
     WHOLE_IMAGE_MAX_RAYS = 1 << 21
+    WHOLE_IMAGE_BYTES_PER_RAY = 12288        # outputs 6.3 KB + workspace ~5 KB per ray at 64 + 64 samples (ops.render_rays), rounded up
+    WHOLE_IMAGE_MEMORY_FRACTION = 0.5        # of the device memory that is free (or cached by torch and unused) when the first chunk arrives
     image_batches = int(os.environ.get("O2345_IMAGE_BATCHES", "4"))
+
+    def whole_image_stats(self):
+        """{"images", "chunks_served", "plain_calls", "fallbacks_by_reason": {...}, "enabled"} of this renderer since construction."""
+        st = self._stats
+        return dict(images=st["images"], chunks_served=st["chunks_served"], plain_calls=st["plain_calls"], fallbacks_by_reason=dict(st["fallbacks_by_reason"]),
+                    enabled=bool(self.whole_image and self._abandoned < 2))
+
+    def _count(self, key, reason=None):
+        for st in (self._stats, WHOLE_IMAGE_TOTALS):
+            if reason is None:
+                st[key] += 1
+            else:
+                st[key][reason] = st[key].get(reason, 0) + 1
+
+    def _max_image_rays(self, dev):
+        """The largest image rendered whole: WHOLE_IMAGE_MAX_RAYS, and no more than fits in WHOLE_IMAGE_MEMORY_FRACTION of the memory that is available now
+        (the reference's 512-ray chunk loop exists to bound memory: an image that fits chunk by chunk must not die here)."""
+        if dev.type != "cuda":
+            return self.WHOLE_IMAGE_MAX_RAYS
+        free, _ = torch.cuda.mem_get_info(dev)
+        avail = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        return int(min(self.WHOLE_IMAGE_MAX_RAYS, self.WHOLE_IMAGE_MEMORY_FRACTION * avail / self.WHOLE_IMAGE_BYTES_PER_RAY))
+
+    def _drop_image(self):
+        """Release the cached image.  Batches still running on the side stream read the scene's tensors and the ray storage, which were allocated on the
+        caller's stream: the caller's stream waits for the side stream first, so nothing the caller frees next can be reused under those kernels."""
+        c, self._image = self._image, None
+        if c is not None and self._side is not None and c["dev"].type == "cuda" and any(not bt["joined"] for bt in c["batches"]):
+            torch.cuda.current_stream(c["dev"]).wait_stream(self._side)
 
     @staticmethod
     def _chunk_of_image(t):
@@ -172,16 +212,23 @@ class SparseNeuSRenderer(nn.Module):
         co, cd = self._chunk_of_image(rays_o), self._chunk_of_image(rays_d)
         store = lambda t: (t.data_ptr(), t._version, t.numel())
         same = lambda t, rec: (t is rec[0] and getattr(t, "_version", None) == rec[1]) or (not torch.is_tensor(t) and not torch.is_tensor(rec[0]) and t == rec[0])
-        ok = (co is not None and cd is not None and co[1] == cd[1] and co[1] == c["next"] * c["n"] and R == min(c["n"], c["R"] - co[1])
-              and store(co[2]) == c["store"][0] and store(cd[2]) == c["store"][1] and (float(perturb) > 0) == c["perturb"]
-              and alpha_inter_ratio == c["air"] and background_rgb == c["bg"] and (self.n_samples, self.n_importance) == c["ns"]
-              and all(t is o and t._version == v for t, (o, v) in zip(args, c["args"])) and same(near, c["near"]) and same(far, c["far"])
-              and self.variance_network.variance is c["var"][0] and c["var"][0]._version == c["var"][1]
-              and sdf_network is c["nets"][0] and rendering_network is c["nets"][1]
-              and sdf_network.sdf_layer.weights_key() == c["wkeys"][0] and rendering_network.weights_key() == c["wkeys"][1]
-              and torch.equal(torch.get_rng_state(), c["states"][c["next"] - 1]))
-        if not ok:
-            self._image = None                               # another image, other arguments, out of order, or somebody drew from the host generator
+        why = None
+        if co is None or cd is None or co[1] != cd[1] or store(co[2]) != c["store"][0] or store(cd[2]) != c["store"][1]:
+            why = "rays"
+        elif co[1] != c["next"] * c["n"] or R != min(c["n"], c["R"] - co[1]):
+            why = "order"
+        elif not ((float(perturb) > 0) == c["perturb"] and alpha_inter_ratio == c["air"] and background_rgb == c["bg"] and (self.n_samples, self.n_importance) == c["ns"]
+                  and all(t is o and t._version == v for t, (o, v) in zip(args, c["args"])) and same(near, c["near"]) and same(far, c["far"])):
+            why = "args"
+        elif not (self.variance_network.variance is c["var"][0] and c["var"][0]._version == c["var"][1]
+                  and sdf_network is c["nets"][0] and rendering_network is c["nets"][1]
+                  and sdf_network.sdf_layer.weights_key() == c["wkeys"][0] and rendering_network.weights_key() == c["wkeys"][1]):
+            why = "weights"
+        elif not torch.equal(torch.get_rng_state(), c["states"][c["next"] - 1]):
+            why = "rng"
+        if why is not None:
+            self._drop_image()                               # another image, other arguments, out of order, or somebody drew from the host generator
+            self._count("fallbacks_by_reason", why)
             if c["next"] <= 1:
                 self._abandoned += 1                         # rendered whole, read once: after two such images in a row the mode switches itself off
             return None
@@ -189,10 +236,12 @@ class SparseNeuSRenderer(nn.Module):
         torch.set_rng_state(c["states"][k])                  # the host generator advances as this chunk's own draws (t_rand, pts_random) would have
         c["next"] = k + 1
         self._abandoned = 0
+        self._count("chunks_served")
         a = co[1]
+        out = self._pack_rows(c, a, a + R, k)
         if a + R >= c["R"]:
-            self._image = None                               # last chunk served: release the image's buffers
-        return self._pack_rows(c, a, a + R, k)
+            self._image = None                               # last chunk served (its batch is joined): release the image's buffers
+        return out
 
     def _pack(self, o, sl, sc, sdf_random, var, inv_s, dev):
         """The reference's returned dict (:609-633) for the rays ``sl`` of the call's sample-major outputs ``o``."""
@@ -204,6 +253,76 @@ class SparseNeuSRenderer(nn.Module):
                 "gradients": o["grad"][:, sl].permute(1, 0, 2), "weights": o["weights"][:, sl].t(), "gradient_error_fine": sc[2],
                 "inside_sphere": o["pm"][:, sl].t(), "sdf": o["sdf"][:, sl].t().reshape(-1, 1), "sdf_random": sdf_random, "blended_color_patch": None,
                 "blended_color_patch_mask": None, "weights_sum_fg": o["weights_sum"][sl, None]}
+
+    def _render_image(self, img, R, dev, scene, nr, fr, inv_s, air, bg, qcam, pin, perturb, near, far, sdf_network, rendering_network, var,
+                      alpha_inter_ratio, background_rgb, args):
+        """The first chunk of an image: every R-ray segment of it in one fused call per batch; caches the image and returns chunk 0's dict."""
+        io_, id_, bases = img
+        Ri = io_.shape[0]
+        K = (Ri + R - 1) // R
+        # An image of >= 8,192 rays goes out in up to `image_batches` batches of whole segments on a SIDE stream: the host draws a batch's random numbers, launches it,
+        # draws the next -- and later, while the trainer pulls chunk after chunk to the host (a .cpu() per chunk on ITS stream), the GPU is still rendering
+        # the following batches.  A chunk waits only for its own batch (one event per batch), not for the image.
+        nb = max(1, min(self.image_batches, Ri // 4096)) if dev.type == "cuda" else 1          # (a batch of >= 4,096 rays runs the streaming sampler kernels)
+        # batch boundaries in chunks: equal batches, except that the LAST one is a third of the others -- what the host does with a batch's chunks (serve + the
+        # trainer's own .cpu() calls, ~0.11 ms per chunk) only overlaps the rendering of LATER batches, so the last batch's share is pure tail
+        if nb > 1 and os.environ.get("O2345_IMAGE_TAIL", "1") not in ("", "0"):
+            big = -(-K * 3 // (3 * nb - 2))
+            starts = [min(K, i * big) for i in range(nb)]
+        else:
+            starts = [min(K, i * ((K + nb - 1) // nb)) for i in range(nb)]
+        starts = sorted(set(starts))
+        bounds = [(k0, k1) for k0, k1 in zip(starts, starts[1:] + [K]) if k1 > k0]
+        cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        if nb > 1:
+            if self._side is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(device=dev)
+            self._side.wait_stream(cur)                                     # the scene's tensors were produced on the caller's stream
+        # the host stream of the K calls of the trainer's loop, in the reference's order: per call t_rand = torch.rand(z_vals.shape) (:506-515, only when
+        # perturb > 0), then pts_random = torch.rand([1024, 3]) (:606); the generator is then put back to where it stands after the FIRST call
+        states, batches = [], []
+        rng_before = torch.get_rng_state()
+        try:
+            for bi, k1 in bounds:
+                a0, a1 = bi * R, min(Ri, k1 * R)
+                t_b = torch.empty(a1 - a0, self.n_samples, pin_memory=pin) if perturb > 0 else None
+                p_b = torch.empty(k1 - bi, 1024, 3, pin_memory=pin)
+                for k in range(bi, k1):
+                    ra, rb = k * R - a0, min(Ri, (k + 1) * R) - a0
+                    if perturb > 0:
+                        t_b[ra:rb] = torch.rand(rb - ra, self.n_samples)
+                    p_b[k - bi] = torch.rand([1024, 3])
+                    states.append(torch.get_rng_state())
+                with (torch.cuda.stream(self._side) if nb > 1 else contextlib.nullcontext()):
+                    o = ops.render_rays(scene, io_[a0:a1], id_[a0:a1], nr, fr, self.n_samples, self.n_importance, inv_s, air, bg, qcam,
+                                        t_rand=t_b.to(dev, non_blocking=True) if perturb > 0 else None, want_scalars=True, segment_rays=R)
+                    pts_random = p_b.to(dev, non_blocking=True).view(-1, 3) * 2 - 1
+                    sdf_random = ops.sdf_mlp(scene["sdf_blob"], scene["vol_cl"], pts_random, variant=0)["sdf"].view(k1 - bi, 1024, 1)
+                    for dead in ("mid_z", "dists", "rgb", "nviews", "alpha_sum", "grad_err"):      # per-sample outputs no returned entry reads: 2.7 of 6.3 KB per ray
+                        o.pop(dead, None)
+                    rows = dict(depth=o["depth"][:, None], color=o["color"], mask=o["color_mask"].view(torch.bool)[:, None], cdf=o["cdf"].t(),
+                                depth_var=o["depth_var"][:, None], weights_sum=o["weights_sum"][:, None], weights_max=o["weights_max"][:, None],
+                                grad=o["grad"].permute(1, 0, 2), weights=o["weights"].t(), pm=o["pm"].t(), sdf=o["sdf"].t())      # ray-major views: a chunk is a row range
+                    ev = None
+                    if nb > 1:
+                        ev = torch.cuda.Event()
+                        ev.record(self._side)
+                batches.append(dict(a0=a0, k0=bi, o=o, rows=rows, sdf_random=sdf_random, event=ev, joined=False))
+        except BaseException:
+            torch.set_rng_state(rng_before)                                  # a failed call must not leave the host generator advanced by a whole image
+            raise
+        torch.set_rng_state(states[0])
+        store = lambda t: (t.data_ptr(), t._version, t.numel())     # (the Python object of a view's base is not guaranteed to be the same one twice)
+        # (scene / bases: the packed weights and ray storages stay alive while cached, so their addresses cannot be handed to other tensors)
+        batch_of = [b for b, (k0, k1) in enumerate(bounds) for _ in range(k0, k1)]
+        self._image = dict(n=R, R=Ri, batch_of=batch_of, next=1, states=states, batches=batches, scene=scene, bases=bases, store=(store(bases[0]), store(bases[1])),
+                           args=[(t, t._version) for t in args], near=(near, getattr(near, "_version", None)), far=(far, getattr(far, "_version", None)),
+                           perturb=float(perturb) > 0, air=alpha_inter_ratio, bg=background_rgb, var=(var, var._version), inv_s=inv_s,
+                           wkeys=(sdf_network.sdf_layer.weights_key(), rendering_network.weights_key()), nets=(sdf_network, rendering_network),
+                           ns=(self.n_samples, self.n_importance), dev=dev)
+        self._count("images")
+        self._count("chunks_served")
+        return self._pack_rows(self._image, 0, R, 0)
 
     @torch.no_grad()
     def render(self, rays_o, rays_d, near, far, sdf_network, rendering_network, perturb_overwrite=-1, background_rgb=None,
@@ -246,73 +365,23 @@ class SparseNeuSRenderer(nn.Module):
         img = None
         if sample_dist is None and self.whole_image and self._abandoned < 2 and R % 64 == 0:
             co, cd = self._chunk_of_image(rays_o), self._chunk_of_image(rays_d)
-            if (co is not None and cd is not None and co[1] == cd[1] == 0 and co[0].shape == cd[0].shape and R < co[0].shape[0] <= self.WHOLE_IMAGE_MAX_RAYS):
+            if (co is not None and cd is not None and co[1] == cd[1] == 0 and co[0].shape == cd[0].shape and R < co[0].shape[0] <= self._max_image_rays(dev)):
                 img = (co[0], cd[0], (co[2], cd[2]))
         if img is not None:
-            io_, id_, bases = img
-            Ri = io_.shape[0]
-            K = (Ri + R - 1) // R
-            # An image of >= 8,192 rays goes out in up to `image_batches` batches of whole segments on a SIDE stream: the host draws a batch's random numbers, launches it,
-            # draws the next -- and later, while the trainer pulls chunk after chunk to the host (a .cpu() per chunk on ITS stream), the GPU is still rendering
-            # the following batches.  A chunk waits only for its own batch (one event per batch), not for the image.
-            nb = max(1, min(self.image_batches, Ri // 4096)) if dev.type == "cuda" else 1          # (a batch of >= 4,096 rays runs the streaming sampler kernels)
-            # batch boundaries in chunks: equal batches, except that the LAST one is a third of the others -- what the host does with a batch's chunks (serve + the
-            # trainer's own .cpu() calls, ~0.11 ms per chunk) only overlaps the rendering of LATER batches, so the last batch's share is pure tail
-            if nb > 1 and os.environ.get("O2345_IMAGE_TAIL", "1") not in ("", "0"):
-                big = -(-K * 3 // (3 * nb - 2))
-                starts = [min(K, i * big) for i in range(nb)]
-            else:
-                starts = [min(K, i * ((K + nb - 1) // nb)) for i in range(nb)]
-            starts = sorted(set(starts))
-            bounds = [(k0, k1) for k0, k1 in zip(starts, starts[1:] + [K]) if k1 > k0]
-            cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
-            if nb > 1:
-                if self._side is None or self._side.device != dev:
-                    self._side = torch.cuda.Stream(device=dev)
-                self._side.wait_stream(cur)                                     # the scene's tensors were produced on the caller's stream
-            # the host stream of the K calls of the trainer's loop, in the reference's order: per call t_rand = torch.rand(z_vals.shape) (:506-515, only when
-            # perturb > 0), then pts_random = torch.rand([1024, 3]) (:606); the generator is then put back to where it stands after the FIRST call
-            states, batches = [], []
-            rng_before = torch.get_rng_state()
             try:
-                for bi, k1 in bounds:
-                    a0, a1 = bi * R, min(Ri, k1 * R)
-                    t_b = torch.empty(a1 - a0, self.n_samples, pin_memory=pin) if perturb > 0 else None
-                    p_b = torch.empty(k1 - bi, 1024, 3, pin_memory=pin)
-                    for k in range(bi, k1):
-                        ra, rb = k * R - a0, min(Ri, (k + 1) * R) - a0
-                        if perturb > 0:
-                            t_b[ra:rb] = torch.rand(rb - ra, self.n_samples)
-                        p_b[k - bi] = torch.rand([1024, 3])
-                        states.append(torch.get_rng_state())
-                    with (torch.cuda.stream(self._side) if nb > 1 else contextlib.nullcontext()):
-                        o = ops.render_rays(scene, io_[a0:a1], id_[a0:a1], nr, fr, self.n_samples, self.n_importance, inv_s, air, bg, qcam,
-                                            t_rand=t_b.to(dev, non_blocking=True) if perturb > 0 else None, want_scalars=True, segment_rays=R)
-                        pts_random = p_b.to(dev, non_blocking=True).view(-1, 3) * 2 - 1
-                        sdf_random = ops.sdf_mlp(scene["sdf_blob"], scene["vol_cl"], pts_random, variant=0)["sdf"].view(k1 - bi, 1024, 1)
-                        rows = dict(depth=o["depth"][:, None], color=o["color"], mask=o["color_mask"].view(torch.bool)[:, None], cdf=o["cdf"].t(),
-                                    depth_var=o["depth_var"][:, None], weights_sum=o["weights_sum"][:, None], weights_max=o["weights_max"][:, None],
-                                    grad=o["grad"].permute(1, 0, 2), weights=o["weights"].t(), pm=o["pm"].t(), sdf=o["sdf"].t())      # ray-major views: a chunk is a row range
-                        ev = None
-                        if nb > 1:
-                            ev = torch.cuda.Event()
-                            ev.record(self._side)
-                    batches.append(dict(a0=a0, k0=bi, o=o, rows=rows, sdf_random=sdf_random, event=ev, joined=False))
-            except BaseException:
-                torch.set_rng_state(rng_before)                                  # a failed call must not leave the host generator advanced by a whole image
-                raise
-            torch.set_rng_state(states[0])
-            store = lambda t: (t.data_ptr(), t._version, t.numel())     # (the Python object of a view's base is not guaranteed to be the same one twice)
-            args = (conditional_volume, conditional_valid_mask_volume, feature_maps, color_maps, w2cs, intrinsics, query_c2w)
-            # (scene / bases: the packed weights and ray storages stay alive while cached, so their addresses cannot be handed to other tensors)
-            batch_of = [b for b, (k0, k1) in enumerate(bounds) for _ in range(k0, k1)]
-            self._image = dict(n=R, R=Ri, batch_of=batch_of, next=1, states=states, batches=batches, scene=scene, bases=bases, store=(store(bases[0]), store(bases[1])),
-                               args=[(t, t._version) for t in args], near=(near, getattr(near, "_version", None)), far=(far, getattr(far, "_version", None)),
-                               perturb=float(perturb) > 0, air=alpha_inter_ratio, bg=background_rgb, var=(var, var._version), inv_s=inv_s,
-                               wkeys=(sdf_network.sdf_layer.weights_key(), rendering_network.weights_key()), nets=(sdf_network, rendering_network),
-                               ns=(self.n_samples, self.n_importance), dev=dev)
-            return self._pack_rows(self._image, 0, R, 0)
+                return self._render_image(img, R, dev, scene, nr, fr, inv_s, air, bg, qcam, pin, perturb, near, far, sdf_network, rendering_network, var,
+                                          alpha_inter_ratio, background_rgb,
+                                          (conditional_volume, conditional_valid_mask_volume, feature_maps, color_maps, w2cs, intrinsics, query_c2w))
+            except torch.cuda.OutOfMemoryError:
+                # the image did not fit after all (the host generator is back where the call found it): this renderer stops speculating, the blocks the attempt
+                # left in torch's cache go back to the driver, and THIS call is served the way the reference serves it -- one 512-ray chunk
+                self._image, self.whole_image = None, False
+                self._count("fallbacks_by_reason", "oom")
+                if self._side is not None:
+                    torch.cuda.current_stream(dev).wait_stream(self._side)
+                torch.cuda.empty_cache()
         # ---- one plain call
+        self._count("plain_calls")
         # stratified jitter exactly as the reference draws it (:506-515): torch.rand(z_vals.shape) on the HOST generator, then moved to the device
         # -> the same numbers as the reference under the same torch.manual_seed; drawn into pinned memory and copied asynchronously (torch's
         # caching host allocator keeps the block until the copy has run), the kernel applies lower + (upper - lower) * t

@@ -74,16 +74,23 @@ def broadcast_state_dicts(state, device=None, src=0):
     """The north star's "optional shared-backbone broadcast": rank ``src`` holds ``state`` = {network name: {key: tensor}} (e.g. read from ONE
     checkpoint file), every other rank passes None and receives an identical copy -- ONE collective on one flat fp32 buffer (< 4 MB for the lod-0
     model: a single RCCL broadcast over xGMI; gloo in the CPU tests) + one small object broadcast for the layout.  The default is for every rank
-    to read the checkpoint itself; this exists for deployments where only one rank can reach the file."""
+    to read the checkpoint itself; this exists for deployments where only one rank can reach the file.  Rank ``src`` may pass an exception instead."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if isinstance(state, BaseException):
+            raise state
         return state
     rank = dist.get_rank()
     layout = None
-    if rank == src:
-        layout = [(n, k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for n, sd in state.items() for k, v in sd.items()]
+    if rank == src:                                # an exception instead of the state: rank src could not produce it -- EVERY rank raises (none is left waiting)
+        layout = ("error", f"{type(state).__name__}: {state}") if isinstance(state, BaseException) else \
+            [(n, k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for n, sd in state.items() for k, v in sd.items()]
     box = [layout]
     dist.broadcast_object_list(box, src=src)
     layout = box[0]
+    if isinstance(layout, tuple) and layout and layout[0] == "error":
+        if rank == src and isinstance(state, BaseException):
+            raise state
+        raise RuntimeError(f"o2345 broadcast_state_dicts: rank {src} failed to produce the weights ({layout[1]})")
     total = sum(int(torch.Size(shp).numel()) for _, _, shp, _ in layout)
     dev = _reduce_device(device)
     if rank == src:

@@ -72,9 +72,11 @@ def test_rules_fire_per_segment(dev, ops, form, lib_instance):
     qcam = torch.from_numpy(sc["query_c2w"][:3, 3].copy()).to(dev)
     inv_s = float(np.exp(2.0))
     whole, parts = _compare(ops, scene, ro, rd, 0.1, 2.0, 16, 64, inv_s, qcam, G, label=form)
-    # the rules did fire, and differently per segment: segment 1 (nothing occupied) evaluated its first ray's samples 0..79 (= all of them: S = 80 < 100) ...
-    assert float(parts[1]["pm"].sum()) == 0 and float((parts[1]["sdf"][:, 0] != 100).float().mean()) > 0.9 and float(parts[1]["scalars"][3]) == 80.0
-    assert float((whole["sdf"][:, G + 1:2 * G] == 100).float().mean()) == 1.0
+    # the rules did fire, and differently per segment: segment 1 (nothing occupied) evaluated its first 100 points in the reference's ray-major order
+    # (pts_mask_bool[:100] on the flattened [N_rays * S] mask, :222-223) -- S = 80 < 100: all 80 samples of its first ray and samples 0..19 of its second ...
+    assert float(parts[1]["pm"].sum()) == 0 and float((parts[1]["sdf"][:, 0] != 100).float().mean()) > 0.9 and float(parts[1]["scalars"][3]) == 100.0
+    assert float((parts[1]["sdf"][:20, 1] != 100).float().mean()) > 0.9 and float((parts[1]["sdf"][20:, 1] == 100).float().mean()) == 1.0
+    assert float((whole["sdf"][:, G + 2:2 * G] == 100).float().mean()) == 1.0
     # ... and the crossing ray's sample list in segment 0 (alone: at most one new sample inside the mask per round -> the new samples keep sdf = 100) differs
     # from the same ray's list in segment 2 (64 copies: the rule does not fire) and in segment 3 (two copies)
     z0, z2, z3 = whole["z_vals"][:, 0], whole["z_vals"][:, 2 * G], whole["z_vals"][:, 3 * G]

@@ -143,3 +143,32 @@ def test_two_rank_ray_split_of_one_image():
     # without a process group the helpers are the identity
     blk = {"depth": torch.arange(5.0)}
     assert sh.broadcast_tensor(blk["depth"]) is blk["depth"] and sh.gather_ray_blocks(blk, 5, 64)["depth"] is blk["depth"]
+
+
+def _bad_ckpt_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sh = importlib.import_module("one-2-3-45_amd.sharding")
+    pipeline = importlib.import_module("one-2-3-45_amd.pipeline")
+    sh.init("gloo")
+    try:
+        pipeline.SceneWeights.from_checkpoint("cpu", "/nonexistent/ckpt_000000.pth" if rank == 0 else None, broadcast=True)
+        q.put((rank, "no error"))
+    except Exception as e:                                  # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}"))
+    sh.barrier()                                            # both ranks are still in step afterwards
+    sh.shutdown()
+
+
+def test_two_rank_checkpoint_failure_reaches_every_rank():
+    """with broadcast=True only rank 0 reads the checkpoint; when that fails (missing file, a checkpoint that needs the full unpickler without
+    the opt-in) the other ranks must not be left waiting in the broadcast -- every rank raises."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_bad_ckpt_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    assert "does not load" in res[0] or "No such file" in res[0], res
+    assert "rank 0 failed to produce the weights" in res[1] and "RuntimeError" in res[1], res

@@ -2,7 +2,7 @@
 # rocprofv3 passes behind profiles/: kernel-trace stats of the bench command, then one --pmc pass per counter group on the
 # full-size network kernels (tools/prof_kernels.py).  Run on the GPU box: bash tools/profile_round.sh <tag>
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 REPO=$PWD

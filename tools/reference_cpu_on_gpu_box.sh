@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 rm -rf _refcopy && mkdir -p _refcopy
 cp -r /root/reference/reconstruction _refcopy/reconstruction
 find _refcopy -name '__pycache__' -prune -exec rm -rf {} +
-CMD="mkdir -p gpurun_out; O2345_COMMIT=$(git rev-parse --short HEAD) O2345_REFERENCE_DIR=\$PWD/_refcopy/reconstruction python tools/time_reference_cpu.py ${1:-25} r05 gpurun_out _gpubox > gpurun_out/cpu_reference_gpubox.log 2>&1; tail -2 gpurun_out/cpu_reference_gpubox.log"
+CMD="mkdir -p gpurun_out; O2345_COMMIT=$(git rev-parse --short HEAD) O2345_REFERENCE_DIR=\$PWD/_refcopy/reconstruction python tools/time_reference_cpu.py ${1:-25} r06 gpurun_out _gpubox > gpurun_out/cpu_reference_gpubox.log 2>&1; tail -2 gpurun_out/cpu_reference_gpubox.log"
 /usr/local/graft/bin/gpurun --timeout ${GPU_TIMEOUT:-1500} -- "$CMD; $2"
 rc=$?
 rm -rf _refcopy

@@ -5,7 +5,7 @@ on the host cores of the same box").  Writes <out dir>/rNN_cpu_reference[_gpubox
 was measured on; bench.py attaches the file whose CPU model and core count are those of the box it runs on (else the newest, with the mismatch stated)
 and refuses files of an older round.
 
-    python tools/time_reference_cpu.py [seconds] [round tag, default r05] [out dir, default profiles] [file suffix, default ""]"""
+    python tools/time_reference_cpu.py [seconds] [round tag, default r06] [out dir, default profiles] [file suffix, default ""]"""
 import importlib
 import json
 import os
@@ -26,7 +26,7 @@ pkg = importlib.import_module("one-2-3-45_amd")
 @torch.no_grad()
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
-    tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
+    tag = sys.argv[2] if len(sys.argv) > 2 else "r06"
     out_dir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")
     suffix = sys.argv[4] if len(sys.argv) > 4 else ""
     torch.set_num_threads(min(32, os.cpu_count() or 1))            # the same cap as bench.py's oracle leg: more threads only add fork / join overhead on these op sizes
