@@ -568,7 +568,7 @@ def dropin_block(dev):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import dropin_bench as DB
     out = {"warm": DB.run(dev, reps=5)}
-    keep = ("import_torch_ms", "hip_context_ms", "load_library_ms", "construct_networks_ms", "export_mesh_first_call_ms", "export_mesh_first_call_stages_ms",
+    keep = ("import_torch_ms", "hip_context_ms", "load_library_ms", "construct_networks_ms", "construct_stages_ms", "construct_incl_checkpoint_stand_in_ms", "export_mesh_first_call_ms", "export_mesh_first_call_stages_ms",
             "val_step_first_call_ms", "export_mesh_warm_ms_median", "val_step_warm_ms_median", "val_step_warm_ms_median_per_chunk_calls", "process_total_s", "cpu_threads", "vertices", "error", "rc")
     for name in ("fresh_process_1", "fresh_process_2"):
         d = DB.cold_subprocess()
@@ -669,15 +669,15 @@ def contract_line(result):
 
 
 def emit(result):
-    """bench_extra.json (next to bench.py and, on a gpurun box, under gpurun_out/), the full record as an earlier stdout line, the contract line LAST."""
+    """bench_extra.json (next to bench.py; $O2345_BENCH_EXTRA_FILE overrides the path), the full record as an earlier stdout line, the contract line LAST."""
     full = json.dumps(result)
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
-        if os.path.isdir(d):
-            try:
-                with open(os.path.join(d, "bench_extra.json"), "w") as f:
-                    f.write(full + "\n")
-            except OSError:
-                pass
+    path = os.environ.get("O2345_BENCH_EXTRA_FILE", os.path.join(ROOT, "bench_extra.json"))       # "" = no file (tests that run bench.py as a subprocess)
+    if path:
+        try:
+            with open(path, "w") as f:
+                f.write(full + "\n")
+        except OSError:
+            pass
     sys.stderr.flush()
     print(full)
     print(contract_line(result), flush=True)

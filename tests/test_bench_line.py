@@ -39,7 +39,7 @@ def test_contract_line_is_small_and_complete():
 
 def test_last_stdout_line_is_the_contract_line(tmp_path, monkeypatch):
     d, _ = _recorded()
-    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setenv("O2345_BENCH_EXTRA_FILE", str(tmp_path / "bench_extra.json"))
     buf = io.StringIO()
     with redirect_stdout(buf):
         bench.emit(d)

@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_two_ranks_on_the_gpu_bare_invocation():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["O2345_BENCH_EXTRA_FILE"] = ""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "2", "--warmup", "1",
                         "--no-cpu", "--vol", "64", "--ray-scale", "1", "--mesh-res", "96"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -96,14 +97,16 @@ def test_eight_ranks_on_the_one_gpu_functional():
     sharing the box's single device (gloo for the clock).  FUNCTIONAL ONLY: the printed rate is eight processes time-slicing one GPU, not a scaling number
     (the line says so: shared_gpu_functional_run)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["O2345_BENCH_EXTRA_FILE"] = ""
     env["OMP_NUM_THREADS"] = "4"                         # eight ranks on one host: no thread oversubscription
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-gpu", "--steps", "1", "--warmup", "1",
                         "--no-cpu", "--vol", "64", "--ray-scale", "1", "--mesh-res", "64"],
                        capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    assert len(lines) == 2 and len(lines[1]) <= 4096, r.stdout[-2000:]            # the full record, then the compact contract line (the last thing on stdout)
+    d, line = json.loads(lines[0]), json.loads(lines[1])
+    assert line["n_gpus"] == 8 and line["value"] == d["value"] and len(line["per_rank_ms"]) == 8 and line["rccl_ranks"] == 8 and line["backend"] == "gloo"
     assert d["n_gpus"] == 8 and d["shared_gpu_functional_run"] is True and d["steps"] == 1 and d["scaling"] == "weak"
     assert d["config"]["parallelism"] == "scenes x8" and d["rccl_ranks"] == 8 and d["backend"] == "gloo"
     assert len(d["per_rank"]) == 8 and sorted(p["rank"] for p in d["per_rank"]) == list(range(8))

@@ -58,6 +58,7 @@ def test_bench_bare_invocation_spawns_ranks():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["O2345_BENCH_EXTRA_FILE"] = ""
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--dry-run"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]

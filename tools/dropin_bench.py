@@ -76,18 +76,33 @@ class TrainerLike:
                     "sdf_network_lod0": recon.SparseSdfNetwork(lod=0, ch_in=56, voxel_size=2.0 / (D - 1), vol_dims=[D, D, D], hidden_dim=128, cost_type="variance_mean",
                                                                d_pyramid_feature_compress=16, regnet_d_out=16, num_sdf_layers=4, multires=6),
                     "variance_network_lod0": recon.SingleVarianceNetwork(0.3), "rendering_network_lod0": recon.GeneralRenderingNetwork(16, 56, True)}
+        self.construct_stages_ms = cs = {}
+        t_ = [time.perf_counter()]
+
+        def lap(name):
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            now = time.perf_counter()
+            cs[name] = round(cs.get(name, 0.0) + (now - t_[0]) * 1e3, 3)
+            t_[0] = now
         with torch.random.fork_rng(devices=[]):
             torch.manual_seed(seed)
             ck = nets()
+            lap("checkpoint_stand_in_modules_cpu")
             g = torch.Generator().manual_seed(seed + 1)
             L = ck["sdf_network_lod0"].sdf_layer
             L.lin1.weight_v.data[:, 128:] += 0.03 * torch.randn(128, 16, generator=g)
             L.lin2.weight_v.data[:, 128:] += 0.03 * torch.randn(128, 16, generator=g)
             ck["variance_network_lod0"].variance.data = torch.tensor(float(variance))
             ckpt = {k: {kk: vv.clone() for kk, vv in n.state_dict().items()} for k, n in ck.items()}
-            mine = {k: n.to(dev) for k, n in nets().items()}
+            lap("checkpoint_stand_in_state_dicts")
+            mine = nets()
+            lap("build_modules_cpu")
+            mine = {k: n.to(dev) for k, n in mine.items()}
+            lap("modules_to_device")
         for k, n in mine.items():
             n.load_state_dict(ckpt[k])
+            lap("load_state_dict+prepack:" + k)
         self.pyramid_feature_network_geometry_lod0 = mine["pyramid_feature_network"]
         self.sdf_network_lod0, self.rendering_network_lod0 = mine["sdf_network_lod0"], mine["rendering_network_lod0"]
         self.variance_network_lod0 = mine["variance_network_lod0"]
@@ -96,6 +111,7 @@ class TrainerLike:
         self.sdf_renderer_lod0 = recon.SparseNeuSRenderer(None, self.sdf_network_lod0, self.variance_network_lod0, self.rendering_network_lod0,
                                                           64, 64, 0, 1.0, alpha_type="div", conf=Conf({"general.base_exp_dir": out_dir}))
         self.n_samples_lod0, self.n_importance_lod0 = 64, 64
+        lap("renderer")
 
     # trainer_generic.py:1104-1125
     def obtain_pyramid_feature_maps(self, imgs):
@@ -252,7 +268,12 @@ def _run(dev, reps, resolution, cold, val, out_dir):
     t0 = time.perf_counter()
     tr = TrainerLike(dev, out_dir=out_dir)
     torch.cuda.synchronize()
-    res["construct_networks_ms"] = (time.perf_counter() - t0) * 1e3
+    # what the runner does (exp_runner_generic_blender_val.py:93-160, 485-512): build the modules, move them to the device, load_state_dict (-> prepack hooks),
+    # build the renderer.  Building the synthetic CHECKPOINT (a second set of modules on the CPU + their state dicts) stands in for torch.load of a file and is
+    # reported separately.
+    res["construct_stages_ms"] = tr.construct_stages_ms
+    res["construct_incl_checkpoint_stand_in_ms"] = (time.perf_counter() - t0) * 1e3
+    res["construct_networks_ms"] = sum(v for k, v in tr.construct_stages_ms.items() if not k.startswith("checkpoint_stand_in"))
     t0 = time.perf_counter()
     sample = make_sample(dev)
     torch.cuda.synchronize()
