@@ -67,3 +67,4 @@ def prepack_resolutions():
     weights are loaded (2 ms each) instead of inside the first extract_fields call; any other resolution is built on first use."""
     v = os.environ.get("O2345_PREPACK_RESOLUTIONS", "256")
     return tuple(int(x) for x in v.replace(",", " ").split())
+

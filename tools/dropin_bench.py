@@ -158,10 +158,17 @@ class TrainerLike:
             st.mark("rendering_network")
             vertices_color, _valid = self.rendering_network_lod0(a, b, c, d)
         st.mark("host_frame_transforms")
+        fine = os.environ.get("O2345_DROPIN_FINE_TIMERS")
+        sub = (lambda n: st.mark("host_frame_transforms:" + n)) if fine else (lambda n: None)
+        sub("scale_mat.cpu")
         sm = sample["scale_mat"].cpu().numpy()
+        sub("scale+shift")
         vertices = vertices * sm[0][0, 0] + sm[0][:3, 3][None]
+        sub("trans_mat.cpu")
         tm = sample["trans_mat"].cpu().numpy()
+        sub("concatenate")
         vh = np.concatenate([vertices, np.ones_like(vertices[:, :1])], axis=1)
+        sub("matmul")
         vertices = np.matmul(tm, vh[:, :, None])[:, :3, 0]
         st.mark("colours_to_host")
         vertices_color = np.array(vertices_color.squeeze(0).cpu() * 255, dtype=np.uint8)
@@ -279,10 +286,13 @@ def _run(dev, reps, resolution, cold, val, out_dir):
     torch.cuda.synchronize()
     res["make_sample_ms"] = (time.perf_counter() - t0) * 1e3
     if cold:
+        import gc
         st = Stages(True)
+        g0 = [s_["collections"] for s_ in gc.get_stats()]
         t0 = time.perf_counter()
         nv, nt = tr.export_mesh_step(sample, resolution, st)
         res["export_mesh_first_call_ms"] = (time.perf_counter() - t0) * 1e3
+        res["export_mesh_first_call_gc_collections_gen0_1_2"] = [s_["collections"] - a for s_, a in zip(gc.get_stats(), g0)]
         res["export_mesh_first_call_stages_ms"] = st.ms()
     else:
         nv, nt = tr.export_mesh_step(sample, resolution)
