@@ -94,8 +94,8 @@ def preload(device):
 
 def _warm_aten(device):
     """The handful of ATen kernels that the UNCHANGED trainer (and the mirrors' glue) launch inside the reference's timing brackets, each once on a tiny tensor:
-    the first launch of an ATen kernel in a process loads its code object (2 - 14 ms each, measured with cProfile on the first export_mesh_step of a fresh
-    process: `contiguous` 12, `sum` 5, `exp` 14, `clip` 13, `arange` 2, `upsample_bilinear2d` 2).  Same operators and dtypes as the call sites:
+    the first launch of an ATen kernel in a process loads its code object (a few ms each: the valid-ray rule's four kernels cost 20 ms in the first
+    rendering_network call of a fresh process without this, tools/dropin_bench.py --cold with O2345_WARM_ATEN=0).  Same operators and dtypes as the call sites:
     trainer_generic.py:1119-1123 (bilinear x4 / x2 up-sampling + cat of the pyramid), :1322 (float64 vertices -> float32 on the device),
     rendering_network.py:122-129 (valid-ray rule), generate_grids.py:4-19 (voxel lattice), the per-chunk normal map of val_step (:528-543)."""
     F = torch.nn.functional

