@@ -797,7 +797,7 @@ def main():
     exhaustive = None
     if world == 1 and config.weight_cull() > 0:
         # the same K scenes once more with the colour network on EVERY occupied sample (weight_cull = 0: the reference's work, the value of rounds 1-4):
-        # the contract's `value` above runs with the tolerance-bounded removal (DESIGN 3.4: a ray's colour moves by <= 7.6e-6); both are on the line
+        # the contract's `value` above runs with the tolerance-bounded removal (DESIGN 3.3: a ray's colour moves by <= 7.6e-6); both are on the line
         old_cull, config.WEIGHT_CULL = config.WEIGHT_CULL, 0.0
         try:
             tx = Timer()

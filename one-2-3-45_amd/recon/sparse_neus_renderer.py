@@ -159,6 +159,9 @@ class SparseNeuSRenderer(nn.Module):
     # "oom" (the image did not fit: the mode switches itself off for this renderer and the call is served as a plain call).
     whole_image = os.environ.get("O2345_WHOLE_IMAGE", "1") not in ("", "0")
     WHOLE_IMAGE_MAX_RAYS = 1 << 21
+    WHOLE_IMAGE_MAX_ABANDONED = 1            # images rendered whole of which only the first chunk was ever asked for, before the mode switches itself off: a caller
+                                             # that passes rays[:512] of a bigger tensor once, or nn.DataParallel's device threads moving the shared host
+                                             # generator (every image would fall back after its first chunk), pays for ONE speculative image, not for every image
     WHOLE_IMAGE_BYTES_PER_RAY = 12288        # outputs 6.3 KB + workspace ~5 KB per ray at 64 + 64 samples (ops.render_rays), rounded up
     WHOLE_IMAGE_MEMORY_FRACTION = 0.5        # of the device memory that is free (or cached by torch and unused) when the first chunk arrives
     image_batches = int(os.environ.get("O2345_IMAGE_BATCHES", "4"))
@@ -167,7 +170,7 @@ class SparseNeuSRenderer(nn.Module):
         """{"images", "chunks_served", "plain_calls", "fallbacks_by_reason": {...}, "enabled"} of this renderer since construction."""
         st = self._stats
         return dict(images=st["images"], chunks_served=st["chunks_served"], plain_calls=st["plain_calls"], fallbacks_by_reason=dict(st["fallbacks_by_reason"]),
-                    enabled=bool(self.whole_image and self._abandoned < 2))
+                    enabled=bool(self.whole_image and self._abandoned < self.WHOLE_IMAGE_MAX_ABANDONED))
 
     def _count(self, key, reason=None):
         for st in (self._stats, WHOLE_IMAGE_TOTALS):
@@ -252,7 +255,7 @@ class SparseNeuSRenderer(nn.Module):
             self._drop_image()                               # another image, other arguments, out of order, or somebody drew from the host generator
             self._count("fallbacks_by_reason", why)
             if c["next"] <= 1:
-                self._abandoned += 1                         # rendered whole, read once: after two such images in a row the mode switches itself off
+                self._abandoned += 1                         # rendered whole, read once: the mode switches itself off for this renderer (WHOLE_IMAGE_MAX_ABANDONED)
             return None
         k = c["next"]
         torch.set_rng_state(c["states"][k])                  # the host generator advances as this chunk's own draws (t_rand, pts_random) would have
@@ -385,7 +388,7 @@ class SparseNeuSRenderer(nn.Module):
         pin = dev.type == "cuda"
         # ---- the FIRST chunk of an image: render every segment now (later chunks: _serve_chunk above)
         img = None
-        if sample_dist is None and self.whole_image and self._abandoned < 2 and R % 64 == 0:
+        if sample_dist is None and self.whole_image and self._abandoned < self.WHOLE_IMAGE_MAX_ABANDONED and R % 64 == 0:
             co, cd = self._chunk_of_image(rays_o), self._chunk_of_image(rays_d)
             if (co is not None and cd is not None and co[1] == cd[1] == 0 and co[0].shape == cd[0].shape and R < co[0].shape[0] <= self._max_image_rays(dev)):
                 img = (co[0], cd[0], (co[2], cd[2]))

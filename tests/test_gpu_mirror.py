@@ -222,7 +222,13 @@ def test_whole_image_behind_the_chunk_loop_equals_the_per_chunk_calls(S, scale):
         torch.rand(3)                                                # somebody else draws from the host generator between two chunks
         got = ren.render(chunks_o[1], chunks_d[1], near, far, S["sdf"], S["rnet"], perturb_overwrite=0, **kw)
         assert ren._image is None and torch.equal(got["color_fine"], want1["color_fine"]) and torch.equal(got["weights"], want1["weights"])
+        # an image of which only the first chunk was served switches the mode off for this renderer (one speculative image, not one per image)
+        assert ren._abandoned == 1 and not ren.whole_image_stats()["enabled"]
         ren.render(chunks_o[0], chunks_d[0], near, far, S["sdf"], S["rnet"], perturb_overwrite=0, **kw)
+        assert ren._image is None
+        ren._abandoned = 0
+        ren.render(chunks_o[0], chunks_d[0], near, far, S["sdf"], S["rnet"], perturb_overwrite=0, **kw)
+        assert ren._image is not None
         got = ren.render(chunks_o[2], chunks_d[2], near, far, S["sdf"], S["rnet"], perturb_overwrite=0, **kw)          # out of order
         ren.whole_image = False
         want2 = ren.render(chunks_o[2], chunks_d[2], near, far, S["sdf"], S["rnet"], perturb_overwrite=0, **kw)
