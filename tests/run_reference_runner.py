@@ -179,7 +179,20 @@ def main():
     rich_print = rich.print
     rich.print = lambda *aa, **kk: builtins.print(*aa, **{k: v for k, v in kk.items() if k in ("sep", "end", "file", "flush")})   # plain text into the tee
     with contextlib.redirect_stdout(Tee(sys.__stdout__, buf)):
-        dropin.main()
+        if os.environ.get("O2345_RUNNER_PROFILE"):                  # host-side view of the trainer's own brackets: what the first step of a fresh process spends where
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            try:
+                dropin.main()
+            finally:
+                pr.disable()
+                st = pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative")
+                for fn in ("export_mesh_step", "validate_colored_mesh", "val_step", "extract_geometry", "compute_view_independent"):
+                    st.print_callees(fn)
+        else:
+            dropin.main()
     rich.print = rich_print
     log = buf.getvalue()
     res = {"mode": ra.mode, "checkpoint": os.path.relpath(ckpt, rec), "iter_step": a.iter_step, "load_fails_printed": "load fails" in log,
