@@ -1,6 +1,6 @@
 """GPU: out-of-bounds WRITE check of the C ABI's kernels.
 
-GPU AddressSanitizer needs xnack+ code objects and HSA_XNACK=1, which this GPU pool refuses (profiles/NOTES.md, "sanitizer"), so the check is done with
+GPU AddressSanitizer needs code objects built for page-fault retry and the matching runtime switch, which this GPU pool refuses (profiles/NOTES.md, "sanitizer"), so the check is done with
 guard bands instead: every device buffer the Python side hands to the library -- outputs, caller-sized workspaces (o2345_render_workspace_bytes,
 o2345_conv2d_workspace_bytes, the two-call marching-cubes protocol), scratch -- is carved out of a larger allocation whose bytes immediately before and
 immediately after the buffer (no rounding: the first byte past numel * itemsize is a canary) are filled with a pattern; after whole scene passes at awkward
