@@ -104,8 +104,10 @@ class SparseNeuSRenderer(nn.Module):
         self.n_samples, self.n_importance, self.n_outside, self.perturb, self.alpha_type = n_samples, n_importance, n_outside, perturb, alpha_type
         self.rendering_projector = Projector()
         self.if_fitted_rendering = False
-        self._image, self._abandoned, self._side = None, 0, None         # whole-image mode (render())
-        self._stats = dict(images=0, chunks_served=0, plain_calls=0, fallbacks_by_reason={})
+        self._image, self._side = None, None                             # whole-image mode (render())
+        # counters and the abandonment count live in ONE dict object: nn.DataParallel re-creates its per-device replicas from this module on every forward
+        # (shallow copies of __dict__), so anything a replica must remember for the next image -- "the mode switched itself off" -- has to be shared by reference
+        self._stats = dict(images=0, chunks_served=0, plain_calls=0, fallbacks_by_reason={}, abandoned=0)
         # the side stream of the whole-image mode: created with the renderer (the first stream a process creates costs 6 ms in the HIP runtime -- not inside
         # the first val_step bracket); the networks are on their device when the trainer builds the renderer (exp_runner_generic_blender_val.py:93-129)
         p = next(iter(sdf_network.parameters()), None) if isinstance(sdf_network, nn.Module) else None
@@ -165,6 +167,14 @@ class SparseNeuSRenderer(nn.Module):
     WHOLE_IMAGE_BYTES_PER_RAY = 12288        # outputs 6.3 KB + workspace ~5 KB per ray at 64 + 64 samples (ops.render_rays), rounded up
     WHOLE_IMAGE_MEMORY_FRACTION = 0.5        # of the device memory that is free (or cached by torch and unused) when the first chunk arrives
     image_batches = int(os.environ.get("O2345_IMAGE_BATCHES", "4"))
+
+    @property
+    def _abandoned(self):
+        return self._stats["abandoned"]
+
+    @_abandoned.setter
+    def _abandoned(self, v):
+        self._stats["abandoned"] = int(v)
 
     def whole_image_stats(self):
         """{"images", "chunks_served", "plain_calls", "fallbacks_by_reason": {...}, "enabled"} of this renderer since construction."""
