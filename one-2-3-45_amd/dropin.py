@@ -5,7 +5,11 @@
 
 An import hook serves the reference's module NAMES from this package: the third-party packages (torchsparse,
 inplace_abn, mcubes, trimesh's PLY export) and the four L1 modules whose classes the runner imports (exp_runner_generic_blender_val.py:16-20).
-Nothing in the reference tree is modified; everything else (trainer_generic, data, confs) is imported from the reference."""
+Nothing in the reference tree is modified; everything else (trainer_generic, data, confs) is imported from the reference.
+
+Without touching the command line (run.py:61-67 builds `python exp_runner_generic_blender_val.py ...` itself and runs it with os.system): put
+``one-2-3-45_amd/autoload`` first on PYTHONPATH -- its sitecustomize.py calls activate() in every interpreter whose script is the reference's runner
+(and in no other: run.py's own process keeps the real trimesh / mcubes)."""
 import importlib
 import importlib.abc
 import importlib.machinery
@@ -98,16 +102,22 @@ def _report_whole_image():
               f"fallbacks by reason: {st['fallbacks_by_reason'] or 'none'}", file=sys.stderr)
 
 
+def activate():
+    """Everything the launcher does before the reference script starts: thread-pool sizes (before anything imports torch: the pools read them at start-up;
+    an explicit OMP_NUM_THREADS of the user wins), the host allocator setting, the import hook, the exit report.  Idempotent."""
+    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(var, str(cpu_threads()))
+    if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):
+        tune_host_allocator()
+        install()
+        import atexit
+        atexit.register(_report_whole_image)
+
+
 def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
-    # before anything imports torch: the thread pools read these at start-up (an explicit OMP_NUM_THREADS of the user wins)
-    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
-        os.environ.setdefault(var, str(cpu_threads()))
-    tune_host_allocator()
-    install()
-    import atexit
-    atexit.register(_report_whole_image)
+    activate()
     script = sys.argv[1]
     sys.argv = sys.argv[1:]
     sys.path.insert(0, os.path.dirname(os.path.abspath(script)))

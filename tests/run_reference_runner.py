@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--variance", type=float, default=0.2)
     ap.add_argument("--hw", type=int, default=256)
     ap.add_argument("--workers", type=int, default=None, help="override the Runner's 4 x batch_size DataLoader workers (0 on the CPU stand-ins)")
+    ap.add_argument("--via-autoload", action="store_true", help="start the runner the way run.py does (run.py:61-67): a child `python exp_runner_generic_blender_val.py ...` "
+                                                                "with one-2-3-45_amd/autoload first on PYTHONPATH -- no `-m o2345_amd.dropin` on the command line")
     ap.add_argument("rest", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     rest = a.rest[1:] if a.rest and a.rest[0] == "--" else a.rest
@@ -159,6 +161,25 @@ def main():
 
     os.chdir(rec)
     out_dir = os.path.join(os.path.abspath(a.work), ra.specific_dataset_name)
+    if a.via_autoload:
+        import subprocess
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "one-2-3-45_amd", "autoload"), ROOT, os.path.join(HERE, "stubs"),
+                                                          os.path.join(HERE, "stubs_site")] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p]))
+        cmd = [sys.executable, "exp_runner_generic_blender_val.py"] + rest                      # run.py's command, verbatim
+        print("RUNNER_COMMAND " + " ".join(cmd) + "   (PYTHONPATH=" + env["PYTHONPATH"] + ")")
+        p = subprocess.run(cmd, cwd=rec, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+        log = p.stdout
+        print(log)
+        res = {"mode": ra.mode, "via_autoload": True, "rc": p.returncode, "checkpoint": os.path.relpath(ckpt, rec), "iter_step": a.iter_step,
+               "load_fails_printed": "load fails" in log, "optimizer_load_fails_printed": "load optimizer fails" in log, "fake_ops": False,
+               "whole_image_report_printed": "o2345 render():" in log}
+        mesh = os.path.join(out_dir, "mesh.ply")
+        if os.path.exists(mesh):
+            mio = importlib.import_module("one-2-3-45_amd.mesh_io")
+            v, f, c = mio.read_ply(mesh)
+            res.update(mesh=mesh, vertices=int(v.shape[0]), triangles=int(f.shape[0]), has_vertex_colours=c is not None)
+        print("RUNNER_RESULT " + json.dumps(res))
+        raise SystemExit(p.returncode)
     sys.argv = ["o2345_amd.dropin", "exp_runner_generic_blender_val.py"] + rest
     buf = io.StringIO()
 

@@ -293,3 +293,40 @@ def test_whole_image_switch_off_survives_data_parallel_replication():
     assert ren._abandoned == 1 and not ren.whole_image_stats()["enabled"] and ren.whole_image_stats()["fallbacks_by_reason"] == {"rng": 1}
     rep2 = ren._replicate_for_data_parallel()                     # the next forward's replica starts switched off
     assert rep2._abandoned == 1 and not rep2.whole_image_stats()["enabled"]
+
+
+def test_autoload_sitecustomize_activates_only_for_the_reference_runner(tmp_path):
+    """run.py builds `python exp_runner_generic_blender_val.py ...` itself and starts it with os.system (run.py:61-67): with one-2-3-45_amd/autoload first on
+    PYTHONPATH the child interpreter gets the import hook (the reference's module names resolve to this package, thread-pool sizes set), while any other
+    script -- run.py's own process with Zero123, SAM and the real trimesh -- is left alone; O2345_AUTOLOAD=0 switches it off."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = textwrap.dedent("""
+        import os, sys
+        try:
+            import torchsparse, torchsparse.nn, inplace_abn, mcubes, trimesh
+            from models.sparse_sdf_network import SparseSdfNetwork
+            from models.sparse_neus_renderer import SparseNeuSRenderer
+            from models.rendering_network import GeneralRenderingNetwork
+            from models.featurenet import FeatureNet
+            print("HOOKED", torchsparse.__name__, SparseSdfNetwork.__module__, FeatureNet.__module__, os.environ.get("OMP_NUM_THREADS"), "sitecustomize_chained" in os.environ)
+        except ImportError as e:
+            print("PLAIN", type(e).__name__)
+    """)
+    (tmp_path / "exp_runner_generic_blender_val.py").write_text(probe)
+    (tmp_path / "run.py").write_text(probe)
+    later = tmp_path / "later"
+    later.mkdir()
+    (later / "sitecustomize.py").write_text("import os\nos.environ['sitecustomize_chained'] = '1'\n")      # a site hook further down the path still runs
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "O2345_AUTOLOAD")}
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "one-2-3-45_amd", "autoload"), root, str(later)])
+    run = lambda script, **kw: subprocess.run([sys.executable, str(tmp_path / script)], capture_output=True, text=True, timeout=300, cwd=tmp_path, env=dict(env, **kw))
+    r = run("exp_runner_generic_blender_val.py")
+    assert r.returncode == 0 and r.stdout.split()[:4] == ["HOOKED", "one-2-3-45_amd.shims.torchsparse", "one-2-3-45_amd.recon.sparse_sdf_network", "one-2-3-45_amd.featurenet"], (r.stdout, r.stderr[-800:])
+    assert r.stdout.split()[4] != "None" and r.stdout.split()[5] == "True"
+    assert run("run.py").stdout.split()[0] == "PLAIN"
+    assert run("exp_runner_generic_blender_val.py", O2345_AUTOLOAD="0").stdout.split()[0] == "PLAIN"
+    assert run("run.py", O2345_AUTOLOAD_SCRIPTS="run.py").stdout.split()[0] == "HOOKED"

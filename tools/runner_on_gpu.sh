@@ -12,7 +12,10 @@ CMD='mkdir -p gpurun_out; L=gpurun_out/runner_dropin.log; : > $L;
 for MODE in "export_mesh --resolution 64" "export_mesh --resolution 256" "val"; do
   echo "=== python -m o2345_amd.dropin exp_runner_generic_blender_val.py --mode $MODE --conf confs/one2345_lod0_val_demo.conf --specific_dataset_name scene0" >> $L;
   ( time timeout 600 python tests/run_reference_runner.py --ref _refcopy/reconstruction --work /tmp/runner_work -- --mode $MODE --conf confs/one2345_lod0_val_demo.conf --specific_dataset_name scene0 ) >> $L 2>&1; echo "rc=$?" >> $L;
-done; grep -c "RUNNER_RESULT" $L; grep "RUNNER_RESULT\|rc=\|real" $L'
+done;
+echo "=== the way run.py starts it (run.py:61-67): python exp_runner_generic_blender_val.py --mode export_mesh --resolution 256 ..., one-2-3-45_amd/autoload first on PYTHONPATH" >> $L;
+( time timeout 600 python tests/run_reference_runner.py --ref _refcopy/reconstruction --work /tmp/runner_work --via-autoload -- --mode export_mesh --resolution 256 --conf confs/one2345_lod0_val_demo.conf --specific_dataset_name scene0 ) >> $L 2>&1; echo "rc=$?" >> $L;
+grep -c "RUNNER_RESULT" $L; grep "RUNNER_RESULT\|rc=\|real" $L'
 /usr/local/graft/bin/gpurun --timeout ${GPU_TIMEOUT:-1500} -- "$CMD; $1"
 rc=$?
 rm -rf _refcopy
