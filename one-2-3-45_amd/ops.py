@@ -110,6 +110,8 @@ def _warm_aten(device):
     g, w = torch.zeros(2, 4, 3, device=device), torch.zeros(2, 4, device=device)
     (g * w[:, :4, None] * w[..., None]).sum(dim=1).detach().cpu()
     (torch.rand(2, 3, pin_memory=True).to(device, non_blocking=True) * 2 - 1).sum()
+    k = torch.eye(3, device=device)[None].repeat(2, 1, 1).clone()              # trainer_generic.py:853-854: intrinsics.clone(); [:, :2] *= 0.25
+    k[:, :2] *= 0.25
 
 
 _ws_cache = {}

@@ -126,6 +126,8 @@ class TrainerLike:
         st.mark("unpack_sample")
         sizeW, sizeH = sample["img_wh"][0][0], sample["img_wh"][0][1]
         imgs = sample["images"][0]
+        intrinsics_l_4x = sample["intrinsics"][0].clone()                                       # :853-854 (unused afterwards in the released configuration, but it runs)
+        intrinsics_l_4x[:, :2] *= 0.25
         true_img = np.uint8(sample["query_image"][0].permute(1, 2, 0).cpu().numpy() * 255)      # noqa: F841  (the trainer converts it before anything else)
         st.mark("featurenet_pyramid")
         with torch.no_grad():
