@@ -565,6 +565,36 @@ def test_render_trained_regime(dev, ops, variance, air, bg, shift, precision):
     assert res["rays_hitting_surface"] > 10, res
 
 
+@pytest.mark.parametrize("variance,air,bg,shift", [(1.0, 1.0, 1.0, -0.2), (1.5, 1.0, None, -0.2), (1.5, 0.5, 1.0, 0.0), (-1.5, 0.5, 1.0, -0.2)])
+def test_render_at_the_clip_limits_of_the_variance(dev, ops, variance, air, bg, shift):
+    """The ends of SingleVarianceNetwork's range as the renderer uses it (sparse_neus_renderer.py:340: inv_s = exp(10 variance) clipped to [1e-6, 1e6]):
+    variance 1.0 -> inv_s 22,026; 1.5 -> the upper clip 1e6 (every section's opacity is a step function of the SDF's sign); -1.5 -> 3e-7, below the lower
+    clip 1e-6 (every section transparent but for the reference's +1e-5).  Same three-clause contract as test_render_trained_regime, every output finite."""
+    import render_check as RC
+    s = small_scene()
+    d = dev_scene(s, dev, ops)
+    sc = s["sc"]
+    a = _oracle_args(s, shift)
+    W = {k: np.array(v) for k, v in s["sdfW"].items()}
+    W["b2"][0] += shift
+    scene = {k: d[k] for k in ("color_mfma_blob", "color_x3_blob", "vol_cl", "maskvol", "cmaps", "proj", "cam_pos")}
+    scene["sdf_blob"] = torch.from_numpy(pkg.weights.pack_sdf_blob(W)).to(dev)
+    ro, rd = rays_for(s, 96, seed=5)
+    near, far = float(sc["query_near_far"][0]), float(sc["query_near_far"][1])
+    inv_s = float(np.clip(np.exp(10.0 * variance), 1e-6, 1e6))
+    assert inv_s in (1e-6, 1e6) or variance == 1.0
+    o = ops.render_rays(scene, torch.from_numpy(ro).to(dev), torch.from_numpy(rd).to(dev), near, far, 64, 64, inv_s, air, 0.0 if bg is None else bg,
+                        torch.from_numpy(sc["query_c2w"][:3, 3].copy()).to(dev))
+    for k in ("color", "depth", "weights", "weights_sum", "weights_max", "depth_var", "cdf", "sdf", "grad"):
+        assert bool(torch.isfinite(o[k]).all()), k
+    assert float(o["weights_sum"].max()) <= 1.0 + 1e-5 and float(o["weights"].min()) >= 0.0
+    if inv_s == 1e-6:
+        assert float(o["weights_sum"].max()) < 0.01                       # nothing but the reference's +1e-5 per section
+    res = RC.three_clause(ops, dev, scene, a, torch.from_numpy(ro), torch.from_numpy(rd), near, far, variance, air, bg, "f16x3", label="clip_limits")
+    if shift < 0 and inv_s > 1:
+        assert res["rays_hitting_surface"] > 10, res
+
+
 def test_ray_finalize_stage_initialises_every_slot(dev, ops):
     """The public stage entry o2345_ray_finalize: the reference's defaults (sdf = 100, gradients = colours = 0, sparse_neus_renderer.py:231) in EVERY
     slot -- occupied ones included, a caller may evaluate only part of the list --, mid points / section lengths / occupancy vs the oracle, and the
